@@ -1,0 +1,452 @@
+"""CPU oracle for the OFDM TX/RX hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy (complex128) restatement of the algorithm of the reference
+repository's hot path (tayloreisman16/LTE-GNU-Radio-Code).  It is the checker the
+HIP kernels are compared against.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it; the product path
+(``lte-gnu-radio-code_amd/``) never does and fails loudly without its HIP library.
+
+Pinning: every function below is checked in ``tests/test_oracle_golden.py`` against
+(i) the reference's own data fixtures (statically extracted, see
+``tests/golden/gen_golden.py``) and (ii) outputs of the reference Python itself, run
+once in the build container by the same script and committed under ``tests/golden``.
+16-QAM / 64-QAM mapping is an extension the reference does not have
+(``OFDM.py:12-15`` knows BPSK/QPSK only): parity UNPINNED for those two maps.
+
+Citations use  G/ = /root/reference/GNU-Radio-Repositories/ :
+  RX   G/gr-utsa_ofdm/python/SynchAndChanEst.py            (authoritative)
+  RXc  G/gr-RXOFDM/python/synch_and_chan_est.py            (compat constants)
+  TX   G/LEGACY/gr-ofdm-rx/python/txrx_mod/MultiAntennaSystem.py
+  ZC   G/LEGACY/gr-ofdm-rx/python/txrx_mod/SynchSignal.py
+  BR   G/LEGACY/gr-ofdm-rx/python/BitRecovery.py
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------- bins / ZC
+
+
+def bins_p(num_bins: int, nfft: int) -> np.ndarray:
+    """Used-bin list, negative frequencies first, DC skipped (RX:38-41,66-70; ZC:13-14)."""
+    h = int(num_bins / 2)
+    neg = list(range(-h, 0, 1))
+    pos = list(range(1, h + 1, 1))
+    return (np.array(neg + pos, dtype=np.int64) + nfft) % nfft
+
+
+def zadoff_chu(mm: int, root: int = 23) -> np.ndarray:
+    """ZC sequence of length MM (RX:52-59, ZC:23-30; root 37 form RXc:54-64)."""
+    x0 = np.arange(0, int(mm), dtype=np.float64)
+    x1 = np.arange(1, int(mm) + 1, dtype=np.float64)
+    if mm % 2 == 0:
+        return np.exp(-1j * (2 * np.pi / mm) * root * (x0 ** 2 / 2))
+    return np.exp(-1j * (2 * np.pi / mm) * root * (x0 * x1) / 2)
+
+
+# --------------------------------------------------------------------------- bit <-> symbol maps
+
+_QPSK_POINTS = np.exp(1j * 2 * np.pi / 8 * np.array([1.0, -1.0, 3.0, 5.0]))  # TX:171-178, BR:45-52
+
+BITS_PER_SYMBOL = {"BPSK": 1, "QPSK": 2, "16QAM": 4, "64QAM": 6}
+
+
+def map_bits(bits: np.ndarray, modulation: str) -> np.ndarray:
+    """bits (flat, 0/1) -> complex symbols, MSB-first per symbol.
+
+    BPSK ``2b-1`` (TX:156-157); QPSK index ``2*b0+b1`` -> exp(j*2pi/8*{1,-1,3,5}) (TX:159-178).
+    16QAM/64QAM: 3GPP TS 36.211 section 7.1 Gray maps, unit average energy (extension, unpinned).
+    """
+    bits = np.asarray(bits).astype(np.int64).ravel()
+    bps = BITS_PER_SYMBOL[modulation]
+    b = bits.reshape(-1, bps)
+    if modulation == "BPSK":
+        return (2 * b[:, 0] - 1).astype(np.complex128)
+    if modulation == "QPSK":
+        return _QPSK_POINTS[2 * b[:, 0] + b[:, 1]]
+    s = 1 - 2 * b  # 0 -> +1, 1 -> -1
+    if modulation == "16QAM":
+        i = s[:, 0] * (2 - s[:, 2])
+        q = s[:, 1] * (2 - s[:, 3])
+        return (i + 1j * q) / np.sqrt(10.0)
+    if modulation == "64QAM":
+        i = s[:, 0] * (4 - s[:, 2] * (2 - s[:, 4]))
+        q = s[:, 1] * (4 - s[:, 3] * (2 - s[:, 5]))
+        return (i + 1j * q) / np.sqrt(42.0)
+    raise ValueError(modulation)
+
+
+def demap_hard(z: np.ndarray, modulation: str) -> np.ndarray:
+    """Hard decision, output bit order [b0, b1, ...] per symbol.
+
+    QPSK: b0 = (Re<0), b1 = (Im<0): the closed form of BitRecovery's
+    ``int(0.5*(sign(llr1-llr0)+1))`` (BR:105-157), see ``bit_recovery`` for the literal form.
+    """
+    z = np.asarray(z).ravel()
+    re, im = z.real, z.imag
+    if modulation == "BPSK":
+        return (re > 0).astype(np.uint8)
+    if modulation == "QPSK":
+        return np.stack([re < 0, im < 0], axis=1).astype(np.uint8).ravel()
+    if modulation == "16QAM":
+        t = 2.0 / np.sqrt(10.0)
+        return np.stack([re < 0, im < 0, np.abs(re) > t, np.abs(im) > t], axis=1).astype(np.uint8).ravel()
+    if modulation == "64QAM":
+        a, c = 4.0 / np.sqrt(42.0), 2.0 / np.sqrt(42.0)
+        return np.stack([re < 0, im < 0, np.abs(re) > a, np.abs(im) > a,
+                         np.abs(np.abs(re) - a) > c, np.abs(np.abs(im) - a) > c],
+                        axis=1).astype(np.uint8).ravel()
+    raise ValueError(modulation)
+
+
+def bit_recovery(z: np.ndarray):
+    """Literal restatement of BitRecovery.work (BR:66-157) for QPSK.
+
+    Returns (hardbit int[2n], softbit0 float[2n], softbit1 float[2n]).
+    """
+    z = np.asarray(z).astype(np.complex64).astype(np.complex128).ravel()
+    n = len(z)
+    cdat = _QPSK_POINTS
+    zobs = z[:, None] - cdat[None, :]                       # BR:82-86
+    dminind = np.argmin(np.abs(zobs), axis=1)               # BR:87
+    dmin = np.min(np.abs(zobs), axis=1)                     # BR:88
+    ez = z - cdat[dminind]                                  # BR:93-98
+    sigma = 0.7071067811865476 * np.mean(np.abs(dmin))      # BR:102
+    dfact = 1.0 / (sigma * sigma)                           # BR:103
+    K = 1.414213562373095                                   # BR:57
+    llrp0 = np.zeros(2 * n)
+    llrp1 = np.zeros(2 * n)
+    near_r = -0.5 * dfact * np.abs(ez.real)
+    far_r = -0.5 * dfact * (K - np.abs(ez.real))
+    near_i = -0.5 * dfact * np.abs(ez.imag)
+    far_i = -0.5 * dfact * (K - np.abs(ez.imag))
+    re, im = z.real, z.imag
+    # quadrant tests in the reference's order (++, -+, --, +-), first match wins (BR:106-125)
+    q1 = (re >= 0) & (im >= 0)
+    q2 = ~q1 & (re <= 0) & (im >= 0)
+    q3 = ~q1 & ~q2 & (re <= 0) & (im <= 0)
+    q4 = ~q1 & ~q2 & ~q3 & (re >= 0) & (im <= 0)
+    re_pos = q1 | q4          # real-bit decided "0" side
+    im_pos = q1 | q2
+    anyq = q1 | q2 | q3 | q4  # NaNs match nothing -> stay 0
+    llrp0[0::2] = np.where(anyq, np.where(re_pos, near_r, far_r), 0.0)
+    llrp1[0::2] = np.where(anyq, np.where(re_pos, far_r, near_r), 0.0)
+    llrp0[1::2] = np.where(anyq, np.where(im_pos, near_i, far_i), 0.0)
+    llrp1[1::2] = np.where(anyq, np.where(im_pos, far_i, near_i), 0.0)
+    hard = (0.5 * (np.sign(llrp1 - llrp0) + 1.0)).astype(int)   # BR:155-156
+    return hard, llrp0, llrp1
+
+
+# --------------------------------------------------------------------------- TX
+
+
+def tx_grid(bits: np.ndarray, nfft: int, num_synch_bins: int, num_data_bins: int,
+            n_sym: int, synch_dat=(1, 3), modulation: str = "QPSK", zc_root: int = 23) -> np.ndarray:
+    """Resource grid (n_sym, nfft): ZC on sync symbols, mapped data on data symbols.
+
+    TX:135-183.  ``synch_state`` never advances (TX:146) so every sync symbol carries
+    ``zc[0:Ks]``.  Bits are consumed data-symbol-major, then bin-major in bins_p order.
+    """
+    S, D = int(synch_dat[0]), int(synch_dat[1])
+    bps = BITS_PER_SYMBOL[modulation]
+    sb = bins_p(num_synch_bins, nfft)
+    db = bins_p(num_data_bins, nfft)
+    zc = zadoff_chu(S * num_synch_bins, zc_root)
+    grid = np.zeros((n_sym, nfft), dtype=np.complex128)
+    bits = np.asarray(bits).ravel()
+    nd = 0
+    for s in range(n_sym):
+        if s % (S + D) < S:
+            grid[s, sb] = zc[0:num_synch_bins]
+        else:
+            chunk = bits[nd * num_data_bins * bps:(nd + 1) * num_data_bins * bps]
+            grid[s, db] = map_bits(chunk, modulation)
+            nd += 1
+    return grid
+
+
+def tx_symbol_synth(grid: np.ndarray, cp_len: int) -> np.ndarray:
+    """IFFT + CP + power normalisation, symbol by symbol (TX:189-218). Returns flat IQ."""
+    n_sym, nfft = grid.shape
+    L = nfft + cp_len
+    out = np.zeros(n_sym * L, dtype=np.complex128)
+    for s in range(n_sym):
+        x = np.fft.ifft(grid[s], nfft)                                   # TX:199
+        t = np.concatenate((x[-cp_len:], x)) if cp_len > 0 else x.copy()  # TX:200-201
+        e = abs(np.dot(t, np.conj(t)))                                   # TX:202
+        if e > 1e-30:                                                    # TX:204
+            t = t * np.sqrt(len(t) / e)                                  # TX:205-207
+        p = np.var(t)                                                    # TX:213
+        out[s * L:(s + 1) * L] = t * (1 / np.sqrt(p))                    # TX:218
+    return out
+
+
+def tx_modulate(bits, nfft, cp_len, num_synch_bins, num_data_bins, n_sym,
+                synch_dat=(1, 3), modulation="QPSK", zc_root=23) -> np.ndarray:
+    """bits -> time-domain IQ (a1+a2+a3)."""
+    return tx_symbol_synth(
+        tx_grid(bits, nfft, num_synch_bins, num_data_bins, n_sym, synch_dat, modulation, zc_root), cp_len)
+
+
+REF_TAPS = np.array([0.3977, 0.7954 - 0.3977j, -0.1988, 0.0994, -0.0398])  # TX:64
+
+
+def channel_apply(tx: np.ndarray, taps: np.ndarray, nfft: int) -> np.ndarray:
+    """y = convolve(tx, taps/||taps|| zero-padded to nfft taps); length +nfft-1 (TX:79-94,221-231)."""
+    h = np.zeros(nfft, dtype=np.complex128)
+    taps = np.asarray(taps, dtype=np.complex128)
+    h[0:len(taps)] = taps / np.linalg.norm(taps)
+    return np.convolve(np.asarray(tx).ravel(), h)
+
+
+def awgn_noise_var(tx: np.ndarray, nfft: int, cp_len: int, num_data_bins: int, bps: int,
+                   snr_db: float, snr_type: str = "Digital") -> float:
+    """Noise variance used by additive_noise (TX:235-248)."""
+    sig_pow = np.var(tx)
+    if snr_type == "Digital":
+        return (1.0 / (num_data_bins * bps)) * (nfft + cp_len) * sig_pow * 10 ** (-snr_db / 10)
+    return sig_pow * 10 ** (-snr_db / 10)
+
+
+# --------------------------------------------------------------------------- RX
+
+
+class RxOracle:
+    """fp64 restatement of SynchAndChanEst (RX:17-262) with the reference's call-to-call state.
+
+    ``compat='utsa'``  : gr-utsa_ofdm semantics (root 23, stride 1, gate param, SNR_lin law).
+    ``compat='rxofdm'``: gr-RXOFDM constants (root 37, stride cp-1, gate 0.4, linear SNR)
+                         applied to the same single-sync control flow (the gr-RXOFDM block itself
+                         crashes under Python 3, RXc:194,253; only its constants are kept).
+    """
+
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins,
+                 snr, scale_factor_gate=0.7, compat="utsa", force_fp64=False):
+        self.force_fp64 = bool(force_fp64)
+        self.num_ofdm_symb = int(num_ofdm_symb)
+        self.nfft = int(nfft)
+        self.cp_len = int(cp_len)
+        self.num_synch_bins = int(num_synch_bins)
+        self.synch_dat = [int(synch_dat[0]), int(synch_dat[1])]
+        self.num_data_bins = int(num_data_bins)
+        self.synch_bins_used_P = bins_p(num_synch_bins, nfft)              # RX:38-41
+        self.bins_used_P = bins_p(num_data_bins, nfft)                     # RX:66-70
+        self.L_synch = len(self.synch_bins_used_P)
+        self.M = [self.synch_dat[0], self.num_synch_bins]                  # RX:48
+        self.MM = int(np.prod(self.M))                                     # RX:49
+        self.compat = compat
+        if compat == "utsa":
+            self.p = 23                                                    # RX:52
+            self.stride_val = 1                                            # RX:77
+            self.gate = float(scale_factor_gate)                           # RX:166
+            self.SNR = snr                                                 # RX:98
+            self.SNR_lin = 10 ** (snr / 20)                                # RX:99 (sic: /20)
+            self.snr_ls = self.SNR_lin                                     # RX:180
+            self.snr_eqsync = self.SNR                                     # RX:214 (plain snr)
+            self.snr_data = self.SNR_lin                                   # RX:245
+        elif compat == "rxofdm":
+            self.p = 37                                                    # RXc:54
+            self.stride_val = self.cp_len - 1                              # RXc:81
+            self.gate = 0.4                                                # RXc:170
+            self.SNR = snr                                                 # RXc:102
+            self.SNR_lin = snr
+            self.snr_ls = snr                                              # RXc:184
+            self.snr_eqsync = snr                                          # RXc:217
+            self.snr_data = snr                                            # RXc:247
+        else:
+            raise ValueError(compat)
+        self.zadoff_chu = zadoff_chu(self.MM, self.p)                      # RX:54-59
+        self.start_samp = self.cp_len                                      # RX:78
+        self.rx_b_len = self.nfft + self.cp_len                            # RX:79
+        # del_mat_exp[d, i] = exp(j 2pi d k_i / N), tiled S times (RX:74-75)
+        self.del_mat_exp = np.tile(
+            np.exp((1j * (2.0 * np.pi / self.nfft)) *
+                   np.outer(np.arange(self.cp_len + 1), self.synch_bins_used_P)), (1, self.M[0]))
+        self.corr_obs = -1                                                 # RX:72
+        self.count = 0                                                     # RX:100
+        self.time_synch_ref = np.zeros(3)                                  # RX:83
+        n = self.num_ofdm_symb
+        self.est_chan_time = np.zeros((n, self.nfft), dtype=complex)       # RX:84
+        self.est_synch_freq = np.zeros((n, self.MM), dtype=complex)        # RX:85
+        self.est_chan_freq_P = np.zeros((n, self.nfft), dtype=complex)     # RX:87
+        self.est_data_freq = np.zeros((n, self.num_data_bins), dtype=complex)  # RX:88
+        self.eq_gain = None
+        self.del_mat = None
+        self.trials_run = 0
+
+    # -- a7: one sync trial ------------------------------------------------------------
+    def sync_trial(self, in0: np.ndarray, P: int):
+        """Returns (del_mat[cp+1], y[MM]) for trial P (RX:145-161), O((cp+1)*MM) form."""
+        S, N, L = self.M[0], self.nfft, self.rx_b_len
+        y = np.zeros(self.MM, dtype=complex)
+        for LL in range(S):
+            a = L * LL + P * self.stride_val + self.start_samp             # RX:146
+            w = in0[a:a + N].astype(np.complex128)                         # RX:148
+            Y = np.fft.fft(w, N)                                           # RX:152
+            y[LL * self.num_synch_bins:(LL + 1) * self.num_synch_bins] = Y[self.synch_bins_used_P]  # RX:153-154
+        p_est = np.sqrt(len(y) / np.sum(y * np.conj(y)))                   # RX:157
+        y = p_est * y                                                      # RX:159
+        # del_mat_exp @ diag(y) @ conj(zc) == del_mat_exp @ (y * conj(zc))   (RX:160-161)
+        del_mat = self.del_mat_exp @ (y * np.conj(self.zadoff_chu))
+        return del_mat, y
+
+    # -- a8: LS estimate + gains -------------------------------------------------------
+    def _accept(self, P, dmax_ind, dmax_val, y):
+        self.corr_obs += 1                                                 # RX:171
+        self.time_synch_ref[0] = P * self.stride_val + self.start_samp    # RX:173
+        self.time_synch_ref[1] = dmax_ind                                  # RX:174
+        self.time_synch_ref[2] = int(dmax_val)                             # RX:175
+        data_recov = self.del_mat_exp[dmax_ind] * y                        # RX:177-178
+        tmp_v1 = data_recov * np.conj(self.zadoff_chu) / (1.0 + 1.0 / self.snr_ls)   # RX:180-181
+        chan_est = np.sum(tmp_v1.reshape(self.M[0], self.L_synch), axis=0) / float(self.M[0])  # RX:183-184
+        chan_est1 = np.zeros(self.nfft, dtype=complex)
+        chan_est1[self.synch_bins_used_P] = chan_est                       # RX:186-187
+        self.est_chan_freq_P[self.corr_obs] = chan_est1                    # RX:188
+        self.est_chan_time[self.corr_obs] = np.fft.ifft(chan_est1, self.nfft)  # RX:202,212
+        chan_mag = chan_est * np.conj(chan_est)                            # RX:213
+        self.eq_gain = np.conj(chan_est) / (1.0 / self.snr_eqsync + chan_mag)   # RX:214-216
+        self.est_synch_freq[self.corr_obs] = np.tile(self.eq_gain, self.M[0]) * data_recov  # RX:217-218
+
+    # -- a9: one data symbol -----------------------------------------------------------
+    def demod_symbol(self, window: np.ndarray) -> np.ndarray:
+        # RX:228-230 hands the complex64 stream slice straight to np.fft.fft.  NumPy >= 2.0 then
+        # transforms in single precision (NumPy 1.x upcast to complex128); the literal form below
+        # follows whichever NumPy is installed, exactly like the reference.  ``force_fp64`` upcasts
+        # first: that is the accuracy yardstick the fp32 HIP kernels are measured against.
+        w = np.asarray(window)
+        if self.force_fp64:
+            w = w.astype(np.complex128)
+        t_vec = np.fft.fft(w, self.nfft)                                   # RX:230
+        x = t_vec[self.bins_used_P]                                        # RX:232
+        p_est0 = np.sqrt(len(x) / np.dot(x, np.conj(x)))                   # RX:233
+        x = x * p_est0                                                     # RX:235
+        x = x * np.exp((1j * (2 * np.pi / self.nfft)) * self.time_synch_ref[1] * self.bins_used_P)  # RX:237-240
+        hd = self.est_chan_freq_P[0][self.bins_used_P]                     # RX:242
+        g = np.conj(hd) / (1.0 / self.snr_data + hd * np.conj(hd))         # RX:244-246
+        return g * x                                                       # RX:248
+
+    def work(self, in0: np.ndarray, out: np.ndarray) -> int:
+        """One call of the block (RX:135-262), including its streaming state quirks."""
+        in0 = np.asarray(in0)
+        n_in = len(in0)
+        S, D = self.synch_dat
+        N, L = self.nfft, self.rx_b_len
+        n_trials = int(np.around(n_in / self.stride_val))                  # RX:139
+        n_unique_symb = int(np.floor(n_in / L))                            # RX:140
+        n_data_symb = int(n_unique_symb * (D / (S + D)))                   # RX:141
+        self.trials_run = 0
+        for P in range(n_trials):                                          # RX:143
+            if S * L + P * self.stride_val + N + self.start_samp < n_in:   # RX:144
+                self.trials_run += 1
+                del_mat, y = self.sync_trial(in0, P)
+                self.del_mat = del_mat
+                dmax_ind = int(np.argmax(np.abs(del_mat)))                 # RX:163
+                dmax_val = np.max(np.abs(del_mat))                         # RX:164
+                if dmax_val > self.gate * self.MM:                         # RX:166
+                    if (P * self.stride_val + self.start_samp - self.time_synch_ref[0] > 2 * self.cp_len + N) \
+                            or self.corr_obs == -1:                        # RX:168-169
+                        self._accept(P, dmax_ind, dmax_val, y)
+                        break                                              # RX:219
+        for P in range(0, n_unique_symb, S + D):                           # RX:221
+            data_ptr = int(self.time_synch_ref[0] + S * L * (P + 1))       # RX:222
+            if self.time_synch_ref[0] + S * L * (P + 1) + N - 1 <= n_in:   # RX:223
+                for n_ in range(D):                                        # RX:225
+                    start = data_ptr + L * n_
+                    self.est_data_freq[P + n_] = self.demod_symbol(in0[start:start + N])   # RX:226-248
+        rows = list(range(3, self.est_data_freq.shape[0], S + D))          # RX:249 (literal 3)
+        data_demod = np.delete(self.est_data_freq, rows, axis=0)           # RX:249-250
+        data_out = np.reshape(data_demod, (1, n_data_symb * self.num_data_bins))   # RX:255
+        if self.count > 0:                                                 # RX:257
+            out[0:data_out.shape[1]] = data_out[0]                         # RX:258
+        self.count += 1                                                    # RX:260
+        self.corr_obs = 0                                                  # RX:261
+        return len(out)                                                    # RX:262
+
+
+def rx_work_faithful_ops(rx: RxOracle, in0: np.ndarray) -> None:
+    """Same maths as ``RxOracle.work`` (fresh instance) but with the reference's OPERATION
+    STRUCTURE: dense ``np.matmul(del_mat_exp, np.diag(y))`` (RX:160), three ``np.diag`` products per
+    data symbol (RX:240,244,248), Python list comprehensions.  Used only as the timed
+    "reference gr-utsa_ofdm NumPy path" CPU baseline in bench.py."""
+    S, D = rx.synch_dat
+    N, L = rx.nfft, rx.rx_b_len
+    n_in = len(in0)
+    n_unique_symb = int(np.floor(n_in / L))
+    for P in range(int(np.around(n_in / rx.stride_val))):
+        if S * L + P * rx.stride_val + N + rx.start_samp < n_in:
+            yv = np.zeros(rx.MM, dtype=complex)
+            for LL in range(S):
+                a = L * LL + P * rx.stride_val + rx.start_samp
+                yv[LL * rx.num_synch_bins:(LL + 1) * rx.num_synch_bins] = \
+                    np.fft.fft(in0[a:a + N].astype(np.complex128), N)[rx.synch_bins_used_P]   # RX:148 copies into a c128 buffer
+            p_est = np.sqrt(len(yv) / sum(np.multiply(yv, np.conj(yv))))
+            yv = p_est * yv
+            tmp_2mat = np.matmul(rx.del_mat_exp, np.diag(yv))
+            del_mat = np.matmul(tmp_2mat, np.conj(rx.zadoff_chu))
+            dmax_ind = int(np.argmax(abs(del_mat)))
+            dmax_val = np.max(abs(del_mat))
+            if dmax_val > rx.gate * rx.MM:
+                rx._accept(P, dmax_ind, dmax_val, yv)
+                break
+    bp = list(rx.bins_used_P)
+    for P in range(0, n_unique_symb, S + D):
+        data_ptr = int(rx.time_synch_ref[0] + S * L * (P + 1))
+        if rx.time_synch_ref[0] + S * L * (P + 1) + N - 1 <= n_in:
+            for n_ in range(D):
+                start = data_ptr + L * n_
+                t_vec = np.fft.fft(in0[start:start + N], N)
+                f0 = t_vec[bp]
+                p0 = np.sqrt(len(f0) / (np.dot(f0, np.conj(f0))))
+                d0 = f0 * p0
+                arg_val = [((1j * (2 * np.pi / N)) * rx.time_synch_ref[1]) * kk for kk in bp]
+                dz = np.matmul(np.diag(d0), np.exp(arg_val))
+                hd = rx.est_chan_freq_P[0][bp]
+                mag = np.matmul(np.diag(hd), np.conj(hd))
+                gz = [1.0 / rx.snr_data + vv for vv in mag]
+                gq = np.divide(np.conj(hd), gz)
+                rx.est_data_freq[P + n_][:] = np.matmul(np.diag(gq), dz)
+
+
+def rx_demod_frames_vectorised(iq: np.ndarray, frame_len: int, cfg: dict) -> np.ndarray:
+    """Honest vectorised CPU baseline for frame-aligned batches (sync hit at P=0 assumed and
+    verified): batched FFT over all symbols + elementwise equalise.  Same maths as
+    ``RxOracle`` (fresh instance per frame).  Returns est_data_freq of shape
+    (n_frames, n_data_sym, Kd) complex128.  Used by bench.py's cpu_baseline leg and tests."""
+    N, cp = cfg["nfft"], cfg["cp_len"]
+    S, D = cfg["synch_dat"]
+    L = N + cp
+    n_frames = len(iq) // frame_len
+    proto = RxOracle(1, N, cp, cfg["num_synch_bins"], (S, D), cfg["num_data_bins"],
+                     cfg["snr"], cfg.get("scale_factor_gate", 0.7))
+    n_sym = frame_len // L
+    n_pat = n_sym // (S + D)
+    fr = np.asarray(iq[:n_frames * frame_len]).reshape(n_frames, frame_len)
+    out = np.zeros((n_frames, n_pat * D, cfg["num_data_bins"]), dtype=complex)
+    sb, db = proto.synch_bins_used_P, proto.bins_used_P
+    zc_c = np.conj(proto.zadoff_chu)
+    for f in range(n_frames):
+        x = fr[f]
+        y = np.concatenate([np.fft.fft(x[L * LL + cp:L * LL + cp + N].astype(np.complex128))[sb]
+                            for LL in range(S)])
+        y = y * np.sqrt(len(y) / np.sum(y * np.conj(y)))
+        c = proto.del_mat_exp @ (y * zc_c)
+        d = int(np.argmax(np.abs(c)))
+        if not np.max(np.abs(c)) > proto.gate * proto.MM:
+            raise RuntimeError("vectorised baseline expects frame-aligned input (sync at P=0)")
+        r = proto.del_mat_exp[d] * y
+        h = np.sum((r * zc_c / (1 + 1 / proto.snr_ls)).reshape(S, -1), axis=0) / S
+        hf = np.zeros(N, dtype=complex)
+        hf[sb] = h
+        hd = hf[db]
+        g = np.conj(hd) / (1 / proto.snr_data + hd * np.conj(hd)) * np.exp(1j * 2 * np.pi / N * d * db)
+        # data windows: tsr0 = cp ; ptr = cp + S*L*(P+1) + L*n
+        idx = []
+        for P in range(0, n_pat * (S + D), S + D):
+            for n_ in range(D):
+                idx.append(cp + S * L * (P + 1) + L * n_)
+        idx = np.asarray(idx)
+        win = x[idx[:, None] + np.arange(N)[None, :]].astype(np.complex128)
+        X = np.fft.fft(win, axis=1)[:, db]
+        X = X * np.sqrt(len(db) / np.sum(X * np.conj(X), axis=1))[:, None]
+        out[f] = X * g[None, :]
+    return out
