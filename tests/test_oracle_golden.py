@@ -120,7 +120,12 @@ def test_vectorised_baseline_equals_oracle(golden):
     cfg = dict(nfft=N, cp_len=cp, synch_dat=(1, 3), num_synch_bins=N - 2, num_data_bins=Kd, snr=snr)
     out = orc.rx_demod_frames_vectorised(iq, len(iq), cfg)
     rows = [r for r in range(n_sym) if r % 4 != 3]
-    assert relerr(out[0], g[tag + "_edf"][rows]) < 1e-11
+    # the recorded reference run used NumPy 2's single-precision FFT for the data symbols (RX:230 on a
+    # complex64 slice): fp32-level agreement with it, fp64-level agreement with the fp64 oracle
+    assert relerr(out[0], g[tag + "_edf"][rows]) < 2e-6
+    rx = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, snr, 0.7, force_fp64=True)
+    rx.work(iq, np.zeros(len(iq), np.complex64))
+    assert relerr(out[0], rx.est_data_freq[rows]) < 1e-11
 
 
 def test_bit_recovery_matches_reference(golden):
