@@ -1,0 +1,169 @@
+/* ofdm_mi355x.h -- C ABI of the MI355X-native OFDM TX/RX hot path (libofdm_mi355x.so).
+ *
+ * Drop-in boundary for tayloreisman16/LTE-GNU-Radio-Code's `ofdm_chain.py` path.  The reference
+ * has no native code and no FFI (its blocks are pure Python/NumPy), so every entry point below
+ * cites the PYTHON interface it replaces; the GNU Radio blocks in
+ * `lte-gnu-radio-code_amd/{utsa_ofdm,RXOFDM,TXOFDM}` bind these symbols with ctypes
+ * (INTEGRATION.md shows the stub).  G/ = GNU-Radio-Repositories/ in the reference tree.
+ *
+ * Conventions
+ *   - plain C types only; complex samples are interleaved float32 pairs (numpy complex64,
+ *     GNU Radio gr_complex); caller allocates every output; no exceptions cross the boundary.
+ *   - every function returns OFDM_OK (0) / a non-negative count, or a negative ofdm_status;
+ *     ofdm_last_error() gives the message of the calling thread's last failure.
+ *   - `d_` arguments are DEVICE pointers (HBM of the handle's GPU), `h_` arguments are HOST pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).  Batch entry
+ *     points are asynchronous on that stream and allocate nothing.
+ *   - a handle owns one HIP stream and its device tables; no global mutable state in the library,
+ *     so different block instances (GNU Radio: one thread per block) may run concurrently.
+ */
+#ifndef OFDM_MI355X_H
+#define OFDM_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDM_ABI_VERSION 1
+
+typedef enum {
+    OFDM_OK = 0,
+    OFDM_ERR_INVALID = -1,      /* bad argument / unsupported configuration                        */
+    OFDM_ERR_HIP = -2,          /* HIP runtime error (no device, launch failure, ...)              */
+    OFDM_ERR_INDEX = -3,        /* the reference would raise IndexError (row >= num_ofdm_symb)     */
+    OFDM_ERR_SHAPE = -4,        /* the reference would raise ValueError (reshape / assignment)     */
+    OFDM_ERR_NOMEM = -5
+} ofdm_status;
+
+typedef enum { OFDM_MOD_BPSK = 1, OFDM_MOD_QPSK = 2, OFDM_MOD_16QAM = 4, OFDM_MOD_64QAM = 6 } ofdm_modulation;
+
+/* Which generation of the reference RX block supplies the constants (SURVEY.md section 2 notes). */
+typedef enum {
+    OFDM_COMPAT_UTSA = 0,   /* G/gr-utsa_ofdm/python/SynchAndChanEst.py: ZC root 23, stride 1, gate arg, SNR_lin=10^(snr/20) */
+    OFDM_COMPAT_RXOFDM = 1  /* G/gr-RXOFDM/python/synch_and_chan_est.py:54,81,170,184: root 37, stride cp-1, gate 0.4, linear snr */
+} ofdm_compat;
+
+typedef enum { OFDM_BITS_NONE = 0, OFDM_BITS_PACKED = 1, OFDM_BITS_UNPACKED = 2 } ofdm_bits_mode;
+
+/* ------------------------------------------------------------------------------------------ RX
+ * ctor arguments of utsa_ofdm.SynchAndChanEst (G/gr-utsa_ofdm/python/SynchAndChanEst.py:17-19). */
+typedef struct {
+    int32_t num_ofdm_symb;     /* rows of est_data_freq kept by the stream block (:88)            */
+    int32_t nfft;              /* 64,128,...,4096                                                  */
+    int32_t cp_len;
+    int32_t num_synch_bins;    /* even, <= nfft                                                    */
+    int32_t synch_S;           /* synch_dat[0]                                                     */
+    int32_t synch_D;           /* synch_dat[1]                                                     */
+    int32_t num_data_bins;     /* even, <= nfft                                                    */
+    double snr;                /* the block's `snr` argument (dB-like, see :99,:214)               */
+    double scale_factor_gate;  /* :166 (ignored for OFDM_COMPAT_RXOFDM: 0.4)                       */
+    int32_t compat;            /* ofdm_compat                                                      */
+    int32_t modulation;        /* ofdm_modulation used by the fused / standalone de-mapper         */
+    int32_t device;            /* HIP device ordinal                                               */
+    int32_t reserved;
+} ofdm_rx_cfg;
+
+typedef struct ofdm_rx ofdm_rx;
+
+/* what work() leaves in the block's inspectable attributes (:83-91,:173-175,:260-261) */
+typedef struct {
+    double time_synch_ref[3];  /* [P*stride+cp, argmax lag, int(max|corr|)]                        */
+    int32_t detected;          /* a sync trial was accepted during THIS call                        */
+    int32_t trials_run;        /* sync trials evaluated during this call                            */
+    int32_t count;             /* number of completed work() calls                                  */
+    int32_t corr_obs;
+    int64_t n_data_items;      /* n_data_symb * num_data_bins values packed at the head of `out`    */
+} ofdm_rx_report;
+
+int ofdm_rx_create(const ofdm_rx_cfg* cfg, ofdm_rx** out);
+int ofdm_rx_destroy(ofdm_rx* h);
+
+/* Replaces SynchAndChanEst.work(input_items, output_items) (:135-262), host buffers, including
+ * the block's call-to-call state (count / corr_obs gating, persistent est_data_freq rows).
+ * `h_in`: n_in complex64 items; `h_out`: n_out complex64 items (GNU Radio sync block: n_out == n_in).
+ * Returns n_out (the reference returns len(output_items[0]), :262) or a negative ofdm_status. */
+int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, int64_t n_out,
+                     ofdm_rx_report* rep);
+
+/* Copies block state to host (complex64 interleaved): what the reference exposes as attributes.
+ * `row` selects the corr_obs row the reference wrote: 0 = estimate of the first detection (the one
+ * the data equaliser keeps using, :242), 1 = estimate of the latest later-call detection (:171,188).
+ * Any pointer may be NULL.  h_chan_freq[nfft]=est_chan_freq_P[row], h_chan_time[nfft]=est_chan_time[row],
+ * h_synch_freq[S*Ks]=est_synch_freq[row], h_eq_gain[Ks]=eq_gain (latest), h_data_freq[num_ofdm_symb*Kd]=est_data_freq. */
+int ofdm_rx_get_state(ofdm_rx* h, int32_t row, float* h_chan_freq, float* h_chan_time, float* h_synch_freq,
+                      float* h_eq_gain, float* h_data_freq);
+
+/* Frame-batched device fast path (benchmarks, multi-GPU shards): every frame is one reference
+ * work() buffer processed with FRESH-instance semantics (own sync search from P=0, own channel
+ * estimate; :143-248).  Frame f occupies d_iq[f*frame_stride .. +frame_len) (complex64 items).
+ * n_pat = floor(floor(frame_len/L)/(S+D)) patterns are demodulated; outputs per frame:
+ *   d_eq   [n_pat*D][Kd] complex64 equalised symbols (rows 3,7,.. of the reference already dropped), may be NULL
+ *   d_bits hard bits of those symbols: packed MSB-first [n_pat*D*Kd*bps/8] bytes or unpacked [..*bps] bytes, may be NULL
+ *   d_tsr  [4] int32: time_synch_ref[0..2], detected flag, may be NULL
+ * Asynchronous on `stream`.  Returns n_pat*D (data symbols per frame) or a negative ofdm_status. */
+int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, int64_t frame_stride,
+                             int64_t frame_len, float* d_eq, uint8_t* d_bits, int32_t bits_mode,
+                             int32_t* d_tsr, void* stream);
+
+/* Per-frame state of the LAST ofdm_rx_demod_frames call, copied to host (synchronises the stream):
+ * h_chan_freq[nfft], h_gain[Kd] (equaliser gain incl. lag de-rotation), h_chan_time[nfft]. NULL = skip. */
+int ofdm_rx_get_frame_state(ofdm_rx* h, int64_t frame, float* h_chan_freq, float* h_gain, float* h_chan_time);
+
+/* Bytes of device workspace the batch path needs for n_frames (allocated lazily, grown on demand
+ * OUTSIDE the asynchronous section: call ofdm_rx_reserve before capturing into a hipGraph). */
+int ofdm_rx_reserve(ofdm_rx* h, int64_t n_frames);
+
+/* ------------------------------------------------------------------------------------------ de-map
+ * Replaces BitRecovery.work (G/LEGACY/gr-ofdm-rx/python/BitRecovery.py:66-189) on device buffers.
+ * d_sym: n complex64; d_hard: n*bps bytes (one bit per byte, order [b0,b1,..] per symbol), may be NULL;
+ * d_soft0/d_soft1: n*bps float32 max-log metrics llrp0/llrp1 (:105-125, QPSK only), may be NULL. */
+int ofdm_demap(ofdm_rx* h, const float* d_sym, int64_t n, int32_t modulation, uint8_t* d_hard,
+               float* d_soft0, float* d_soft1, void* stream);
+
+/* ------------------------------------------------------------------------------------------ TX
+ * Replaces MultiAntennaSystem.multi_ant_binary_map + multi_ant_symb_gen (single antenna)
+ * (G/LEGACY/gr-ofdm-rx/python/txrx_mod/MultiAntennaSystem.py:113-218) and SynchSignal (:13-30). */
+typedef struct {
+    int32_t nfft, cp_len, num_synch_bins, num_data_bins, synch_S, synch_D;
+    int32_t modulation;        /* ofdm_modulation */
+    int32_t zc_root;           /* 23 (SynchSignal.py:23) */
+    int32_t device;
+    int32_t reserved;
+} ofdm_tx_cfg;
+
+typedef struct ofdm_tx ofdm_tx;
+
+int ofdm_tx_create(const ofdm_tx_cfg* cfg, ofdm_tx** out);
+int ofdm_tx_destroy(ofdm_tx* h);
+
+/* bits -> time-domain IQ.  Each frame has n_sym symbols laid out back to back (symbol s is a sync
+ * symbol iff s % (S+D) < S); frame f is written at d_iq[f*frame_stride ..] (n_sym*(nfft+cp) items).
+ * d_bits: per frame n_data_sym*Kd*bps bits, one per byte (bits_mode UNPACKED) or MSB-first packed. */
+int ofdm_tx_modulate_frames(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode, int64_t n_frames,
+                            int32_t n_sym, float* d_iq, int64_t frame_stride, void* stream);
+
+/* Loop-back channel (MultiAntennaSystem.py:221-260): y = x (*) taps (taps used as given; the
+ * reference normalises to unit norm first, :86) + complex AWGN of variance noise_var (Philox
+ * counter-based, reproducible from `seed`).  Per frame: in_len input samples, out_len outputs
+ * (out_len <= in_len + n_taps - 1, the rest of the convolution tail is dropped).
+ * d_taps: [n_taps] complex64, or [n_frames][n_taps] when per_frame_taps != 0. */
+int ofdm_channel_apply(ofdm_tx* h, const float* d_in, int64_t n_frames, int64_t in_stride, int64_t in_len,
+                       const float* d_taps, int32_t n_taps, int32_t per_frame_taps, float noise_var,
+                       uint64_t seed, float* d_out, int64_t out_stride, int64_t out_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------ misc */
+int ofdm_abi_version(void);
+const char* ofdm_last_error(void);
+/* plain device memory helpers so hosts without torch can drive the batch path */
+int ofdm_device_malloc(int32_t device, void** d_ptr, int64_t bytes);
+int ofdm_device_free(int32_t device, void* d_ptr);
+int ofdm_memcpy_h2d(int32_t device, void* d_dst, const void* h_src, int64_t bytes);
+int ofdm_memcpy_d2h(int32_t device, void* h_dst, const void* d_src, int64_t bytes);
+int ofdm_device_synchronize(int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDM_MI355X_H */

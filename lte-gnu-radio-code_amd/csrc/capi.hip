@@ -1,0 +1,679 @@
+// capi.hip -- C ABI of libofdm_mi355x.so (declared in include/ofdm_mi355x.h).
+// Host-side logic only: handle/state management, the reference's stream-block control flow
+// (SynchAndChanEst.work, gr-utsa_ofdm/python/SynchAndChanEst.py:135-262) and kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ofdm_mi355x.h"
+#include "ofdm_launch.hpp"
+
+using namespace ofdm;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(OFDM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+bool supported_nfft(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+
+std::vector<cf> make_twiddles(int n) {
+    std::vector<cf> t(n);
+    for (int j = 0; j < n; ++j) {
+        const double a = -2.0 * M_PI * double(j) / double(n);
+        t[j] = cf{float(std::cos(a)), float(std::sin(a))};
+    }
+    return t;
+}
+
+// SynchAndChanEst.py:52-59 / SynchSignal.py:23-30 (root 23) ; synch_and_chan_est.py:54-64 (root 37)
+std::vector<cf> make_zc(int mm, int root, int parity_of) {
+    std::vector<cf> z(mm);
+    for (int n = 0; n < mm; ++n) {
+        const double x0 = double(n), x1 = double(n + 1);
+        const double q = (parity_of % 2 == 0) ? (x0 * x0 / 2.0) : (x0 * x1 / 2.0);
+        const double a = -(2.0 * M_PI / double(mm)) * double(root) * q;
+        z[n] = cf{float(std::cos(a)), float(std::sin(a))};
+    }
+    return z;
+}
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return OFDM_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(OFDM_ERR_NOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    return OFDM_OK;
+}
+
+}  // namespace
+
+struct ofdm_rx {
+    ofdm_rx_cfg cfg{};
+    hipStream_t stream = nullptr;
+    RxDev dev{};
+    cf* d_tw = nullptr;
+    cf* d_zc = nullptr;
+    // ---- stream block state (SynchAndChanEst.py:72,83-100)
+    int count = 0;
+    int corr_obs = -1;
+    double tsr[3] = {0, 0, 0};
+    cf* d_in = nullptr;
+    int64_t in_cap = 0;
+    cf* d_edf = nullptr;                 // est_data_freq [num_ofdm_symb][Kd]
+    int* s_tsr = nullptr;                // [4]
+    cf* s_H = nullptr;                   // [2][N]   rows 0 / 1 of est_chan_freq_P
+    cf* s_htime = nullptr;               // [2][N]
+    cf* s_esf = nullptr;                 // [2][MM]
+    cf* s_eqg = nullptr;                 // [Ks]
+    cf* s_gain = nullptr;                // [Kd]
+    cf* s_ysc = nullptr;                 // [MM]
+    float* d_trial_m = nullptr;
+    int* d_trial_d = nullptr;
+    static constexpr int TRIAL_CAP = 1024;
+    double* d_partial = nullptr;
+    // ---- batch (frame) workspace
+    int64_t cap_frames = 0;
+    int* f_tsr = nullptr;
+    cf* f_H = nullptr;
+    cf* f_gain = nullptr;
+    cf* f_htime = nullptr;
+};
+
+struct ofdm_tx {
+    ofdm_tx_cfg cfg{};
+    hipStream_t stream = nullptr;
+    TxDev dev{};
+    cf* d_tw = nullptr;
+    cf* d_zc = nullptr;
+};
+
+extern "C" {
+
+int ofdm_abi_version(void) { return OFDM_ABI_VERSION; }
+const char* ofdm_last_error(void) { return g_last_error.c_str(); }
+
+int ofdm_device_malloc(int32_t device, void** d_ptr, int64_t bytes) {
+    if (!d_ptr || bytes < 0) return fail(OFDM_ERR_INVALID, "ofdm_device_malloc: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = hipMalloc(d_ptr, size_t(bytes));
+    if (e != hipSuccess) return fail(OFDM_ERR_NOMEM, "hipMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e));
+    return OFDM_OK;
+}
+int ofdm_device_free(int32_t device, void* d_ptr) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(d_ptr));
+    return OFDM_OK;
+}
+int ofdm_memcpy_h2d(int32_t device, void* d_dst, const void* h_src, int64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(d_dst, h_src, size_t(bytes), hipMemcpyHostToDevice));
+    return OFDM_OK;
+}
+int ofdm_memcpy_d2h(int32_t device, void* h_dst, const void* d_src, int64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(h_dst, d_src, size_t(bytes), hipMemcpyDeviceToHost));
+    return OFDM_OK;
+}
+int ofdm_device_synchronize(int32_t device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return OFDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ RX
+int ofdm_rx_destroy(ofdm_rx* h) {
+    if (!h) return OFDM_OK;
+    hipSetDevice(h->cfg.device);
+    void* ptrs[] = {h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
+                    h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return OFDM_OK;
+}
+
+int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
+    if (!c || !out) return fail(OFDM_ERR_INVALID, "ofdm_rx_create: null argument");
+    *out = nullptr;
+    if (!supported_nfft(c->nfft)) return fail(OFDM_ERR_INVALID, "nfft=%d unsupported (64,128,...,4096)", c->nfft);
+    if (c->cp_len < 0 || c->cp_len >= c->nfft) return fail(OFDM_ERR_INVALID, "cp_len=%d out of range", c->cp_len);
+    if (c->num_synch_bins < 2 || c->num_synch_bins > c->nfft || (c->num_synch_bins & 1))
+        return fail(OFDM_ERR_INVALID, "num_synch_bins=%d must be even and in [2, nfft]", c->num_synch_bins);
+    if (c->num_data_bins < 2 || c->num_data_bins > c->nfft || (c->num_data_bins & 1))
+        return fail(OFDM_ERR_INVALID, "num_data_bins=%d must be even and in [2, nfft]", c->num_data_bins);
+    if (c->synch_S < 1 || c->synch_D < 1) return fail(OFDM_ERR_INVALID, "synch_dat must be [>=1, >=1]");
+    if (c->num_ofdm_symb < 1) return fail(OFDM_ERR_INVALID, "num_ofdm_symb must be >= 1");
+    if (c->modulation != 1 && c->modulation != 2 && c->modulation != 4 && c->modulation != 6)
+        return fail(OFDM_ERR_INVALID, "modulation must be 1, 2, 4 or 6 bits per symbol");
+    if (c->compat == OFDM_COMPAT_RXOFDM && c->cp_len < 2)
+        return fail(OFDM_ERR_INVALID, "gr-RXOFDM search stride is cp_len-1: cp_len must be >= 2");
+    if (c->compat != OFDM_COMPAT_UTSA && c->compat != OFDM_COMPAT_RXOFDM) return fail(OFDM_ERR_INVALID, "bad compat");
+
+    HIP_TRY(hipSetDevice(c->device));
+    ofdm_rx* h = new (std::nothrow) ofdm_rx();
+    if (!h) return fail(OFDM_ERR_NOMEM, "out of host memory");
+    h->cfg = *c;
+    const int N = c->nfft, Ks = c->num_synch_bins, Kd = c->num_data_bins, S = c->synch_S;
+    const int MM = S * Ks;
+    RxDev& d = h->dev;
+    d.nfft = N;
+    d.cp = c->cp_len;
+    d.L = N + c->cp_len;
+    d.Ks = Ks;
+    d.Kd = Kd;
+    d.S = S;
+    d.D = c->synch_D;
+    d.MM = MM;
+    d.bps = c->modulation;
+    double snr_ls, snr_eq, snr_data, gate;
+    int root;
+    if (c->compat == OFDM_COMPAT_UTSA) {
+        const double snr_lin = std::pow(10.0, c->snr / 20.0);     // SynchAndChanEst.py:99 (sic: /20)
+        snr_ls = snr_lin;                                          // :180
+        snr_eq = c->snr;                                           // :214 uses the raw argument
+        snr_data = snr_lin;                                        // :245
+        gate = c->scale_factor_gate;                               // :166
+        d.stride = 1;                                              // :77
+        root = 23;                                                 // :52
+    } else {
+        snr_ls = snr_eq = snr_data = c->snr;                       // synch_and_chan_est.py:184,217,247
+        gate = 0.4;                                                // :170
+        d.stride = c->cp_len - 1;                                  // :81
+        root = 37;                                                 // :54
+    }
+    d.gate_mm = float(gate * double(MM));
+    d.inv_ls = float(1.0 / (double(S) * (1.0 + 1.0 / snr_ls)));
+    d.inv_snr_data = float(1.0 / snr_data);
+    d.inv_snr_eqsync = float(1.0 / snr_eq);
+
+    int rc = OFDM_OK;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rc = fail(OFDM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    auto tw = make_twiddles(N);
+    // utsa: parity of MM decides the ZC form (:56); gr-RXOFDM: parity of num_synch_bins (synch_and_chan_est.py:56-61)
+    auto zc = make_zc(MM, root, c->compat == OFDM_COMPAT_UTSA ? MM : Ks);
+    const size_t rows = size_t(c->num_ofdm_symb);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_edf, rows * Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_tsr, 4);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_H, size_t(2) * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_htime, size_t(2) * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_esf, size_t(2) * MM);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_eqg, size_t(Ks));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_gain, size_t(Kd));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_ysc, size_t(MM));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_m, size_t(ofdm_rx::TRIAL_CAP));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_d, size_t(ofdm_rx::TRIAL_CAP));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_partial, size_t(DEMAP_PARTIALS));
+    if (rc == OFDM_OK) {
+        bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemset(h->d_edf, 0, rows * Kd * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->s_tsr, 0, 4 * sizeof(int)) == hipSuccess &&
+                  hipMemset(h->s_H, 0, size_t(2) * N * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->s_htime, 0, size_t(2) * N * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->s_esf, 0, size_t(2) * MM * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->s_eqg, 0, size_t(Ks) * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->s_gain, 0, size_t(Kd) * sizeof(cf)) == hipSuccess;
+        if (!ok) rc = fail(OFDM_ERR_HIP, "device table initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (rc != OFDM_OK) {
+        std::string keep = g_last_error;
+        ofdm_rx_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    d.tw = h->d_tw;
+    d.zc = h->d_zc;
+    *out = h;
+    return OFDM_OK;
+}
+
+int ofdm_rx_reserve(ofdm_rx* h, int64_t n_frames) {
+    if (!h || n_frames < 0) return fail(OFDM_ERR_INVALID, "ofdm_rx_reserve: bad argument");
+    if (n_frames <= h->cap_frames) return OFDM_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    for (void* p : {(void*)h->f_tsr, (void*)h->f_H, (void*)h->f_gain, (void*)h->f_htime})
+        if (p) hipFree(p);
+    h->f_tsr = nullptr;
+    h->f_H = h->f_gain = h->f_htime = nullptr;
+    h->cap_frames = 0;
+    int rc = dev_alloc(&h->f_tsr, size_t(n_frames) * 4);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->f_H, size_t(n_frames) * h->dev.nfft);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->f_gain, size_t(n_frames) * h->dev.Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->f_htime, size_t(n_frames) * h->dev.nfft);
+    if (rc != OFDM_OK) return rc;
+    h->cap_frames = n_frames;
+    return OFDM_OK;
+}
+
+int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, int64_t frame_stride,
+                             int64_t frame_len, float* d_eq, uint8_t* d_bits, int32_t bits_mode, int32_t* d_tsr,
+                             void* stream) {
+    if (!h || !d_iq || n_frames < 0 || frame_len < 0 || frame_stride < frame_len)
+        return fail(OFDM_ERR_INVALID, "ofdm_rx_demod_frames: bad argument");
+    const RxDev& d = h->dev;
+    const int SD = d.S + d.D;
+    const int64_t n_unique = frame_len / d.L;
+    const int64_t n_pat = n_unique / SD;
+    const int64_t n_dsym = n_pat * d.D;
+    if (n_frames > INT32_MAX / 8 || n_dsym > INT32_MAX / 8) return fail(OFDM_ERR_INVALID, "batch too large");
+    if (d_bits) {
+        if (bits_mode != OFDM_BITS_PACKED && bits_mode != OFDM_BITS_UNPACKED)
+            return fail(OFDM_ERR_INVALID, "bits_mode must be OFDM_BITS_PACKED or OFDM_BITS_UNPACKED");
+        if (bits_mode == OFDM_BITS_PACKED && ((d.Kd & 3) || (d.bps & 1)))
+            return fail(OFDM_ERR_INVALID, "packed bits need num_data_bins %% 4 == 0 and an even number of bits per symbol");
+    }
+    if (n_frames == 0) return n_dsym;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (n_frames > h->cap_frames) {
+        int rc = ofdm_rx_reserve(h, n_frames);
+        if (rc != OFDM_OK) return rc;
+    }
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+
+    SyncArgs sa{};
+    sa.iq = reinterpret_cast<const cf*>(d_iq);
+    sa.frame_stride = frame_stride;
+    sa.frame_len = frame_len;
+    sa.n_frames = int(n_frames);
+    sa.mode = 0;
+    sa.p_begin = 0;
+    sa.p_count = 0;
+    sa.force_accept = 0;
+    sa.tsr = h->f_tsr;
+    sa.H = h->f_H;
+    sa.H_for_gain = nullptr;
+    sa.gain = h->f_gain;
+    sa.htime = h->f_htime;
+    HIP_TRY(launch_rx_sync(d, sa, s));
+
+    if (n_dsym > 0 && (d_eq || d_bits)) {
+        DemodArgs da{};
+        da.iq = sa.iq;
+        da.frame_stride = frame_stride;
+        da.frame_len = frame_len;
+        da.n_frames = int(n_frames);
+        da.tsr = h->f_tsr;
+        da.gain = h->f_gain;
+        da.eq = reinterpret_cast<cf*>(d_eq);
+        da.bits = d_bits;
+        da.bits_mode = bits_mode;
+        da.mod = d.bps;
+        da.n_dsym = int(n_dsym);
+        const int64_t total = n_frames * n_dsym;
+        int64_t spc = total / 16384;
+        if (spc < 1) spc = 1;
+        if (spc > n_dsym) spc = n_dsym;
+        da.spc = int(spc);
+        da.chunks_per_frame = int((n_dsym + spc - 1) / spc);
+        da.row_stride_pat = d.D;
+        da.rows_per_frame = int(n_dsym);
+        da.zero_skipped = 1;
+        HIP_TRY(launch_rx_demod(d, da, s));
+    }
+    if (d_tsr) HIP_TRY(hipMemcpyAsync(d_tsr, h->f_tsr, size_t(n_frames) * 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
+    return n_dsym;
+}
+
+int ofdm_rx_get_frame_state(ofdm_rx* h, int64_t frame, float* h_chan_freq, float* h_gain, float* h_chan_time) {
+    if (!h || frame < 0 || frame >= h->cap_frames) return fail(OFDM_ERR_INVALID, "ofdm_rx_get_frame_state: bad frame");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int N = h->dev.nfft, Kd = h->dev.Kd;
+    if (h_chan_freq) HIP_TRY(hipMemcpy(h_chan_freq, h->f_H + frame * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_gain) HIP_TRY(hipMemcpy(h_gain, h->f_gain + frame * Kd, size_t(Kd) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_chan_time) HIP_TRY(hipMemcpy(h_chan_time, h->f_htime + frame * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
+    return OFDM_OK;
+}
+
+int ofdm_rx_get_state(ofdm_rx* h, int32_t row, float* h_chan_freq, float* h_chan_time, float* h_synch_freq,
+                      float* h_eq_gain, float* h_data_freq) {
+    if (!h || row < 0 || row > 1) return fail(OFDM_ERR_INVALID, "ofdm_rx_get_state: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int N = h->dev.nfft, Kd = h->dev.Kd, Ks = h->dev.Ks, MM = h->dev.MM;
+    if (h_chan_freq) HIP_TRY(hipMemcpy(h_chan_freq, h->s_H + size_t(row) * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_chan_time) HIP_TRY(hipMemcpy(h_chan_time, h->s_htime + size_t(row) * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_synch_freq) HIP_TRY(hipMemcpy(h_synch_freq, h->s_esf + size_t(row) * MM, size_t(MM) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_eq_gain) HIP_TRY(hipMemcpy(h_eq_gain, h->s_eqg, size_t(Ks) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_data_freq)
+        HIP_TRY(hipMemcpy(h_data_freq, h->d_edf, size_t(h->cfg.num_ofdm_symb) * Kd * sizeof(cf), hipMemcpyDeviceToHost));
+    return OFDM_OK;
+}
+
+int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, int64_t n_out, ofdm_rx_report* rep) {
+    if (!h || (!h_in && n_in > 0) || (!h_out && n_out > 0) || n_in < 0 || n_out < 0)
+        return fail(OFDM_ERR_INVALID, "ofdm_rx_work: bad argument");
+    const RxDev& d = h->dev;
+    const int N = d.nfft, L = d.L, S = d.S, D = d.D, Kd = d.Kd, SD = S + D;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = h->stream;
+
+    if (n_in > h->in_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (h->d_in) hipFree(h->d_in);
+        h->d_in = nullptr;
+        h->in_cap = 0;
+        const int64_t cap = n_in + n_in / 4 + 1024;
+        int rc = dev_alloc(&h->d_in, size_t(cap));
+        if (rc != OFDM_OK) return rc;
+        h->in_cap = cap;
+    }
+    if (n_in > 0) HIP_TRY(hipMemcpyAsync(h->d_in, h_in, size_t(n_in) * sizeof(cf), hipMemcpyHostToDevice, s));
+
+    const int64_t n_unique = n_in / L;                                       // :140
+    const int64_t n_data_symb = int64_t(double(n_unique) * (double(D) / double(SD)));   // :141 int(n * (D/(S+D)))
+
+    // ---------------- Loop A: sliding sync search, first accepted trial wins (:143-219)
+    int detected = 0, trials_run = 0;
+    {
+        // trial P is evaluated iff S*L + P*stride + N + cp < n_in (:144) and P < round(n_in/stride) (:139,143)
+        const int64_t n_trials = int64_t(std::nearbyint(double(n_in) / double(d.stride)));
+        const int64_t lim = n_in - (int64_t(S) * L + N + d.cp);             // P*stride < lim
+        int64_t p_valid = lim > 0 ? (lim + d.stride - 1) / d.stride : 0;    // number of valid P: P < ceil(lim/stride)
+        if (p_valid > n_trials) p_valid = n_trials;
+        int64_t p0 = 0;
+        int win = 128;
+        std::vector<float> tm(ofdm_rx::TRIAL_CAP);
+        std::vector<int> td(ofdm_rx::TRIAL_CAP);
+        while (p0 < p_valid && !detected) {
+            const int cnt = int(std::min<int64_t>(win, p_valid - p0));
+            SyncArgs sa{};
+            sa.iq = h->d_in;
+            sa.frame_stride = n_in;
+            sa.frame_len = n_in;
+            sa.n_frames = 1;
+            sa.mode = 1;
+            sa.p_begin = int(p0);
+            sa.p_count = cnt;
+            sa.trial_m = h->d_trial_m;
+            sa.trial_d = h->d_trial_d;
+            HIP_TRY(launch_rx_sync(d, sa, s));
+            HIP_TRY(hipMemcpyAsync(tm.data(), h->d_trial_m, size_t(cnt) * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(td.data(), h->d_trial_d, size_t(cnt) * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (int w = 0; w < cnt; ++w) {
+                const int64_t P = p0 + w;
+                ++trials_run;
+                if (tm[w] > d.gate_mm) {                                                    // :166
+                    const double pos = double(P * d.stride + d.cp);
+                    if (h->corr_obs == -1 || pos - h->tsr[0] > double(2 * d.cp + N)) {      // :168-169
+                        // finalize this trial on the device: LS estimate, gains, est_chan_time (:171-218)
+                        h->corr_obs += 1;                                                    // :171
+                        const int row = h->corr_obs > 1 ? 1 : h->corr_obs;
+                        if (h->corr_obs >= h->cfg.num_ofdm_symb)
+                            return fail(OFDM_ERR_INDEX, "est_chan_freq_P has %d rows, corr_obs=%d (the reference raises IndexError)",
+                                        h->cfg.num_ofdm_symb, h->corr_obs);
+                        SyncArgs fa{};
+                        fa.iq = h->d_in;
+                        fa.frame_stride = n_in;
+                        fa.frame_len = n_in;
+                        fa.n_frames = 1;
+                        fa.mode = 0;
+                        fa.p_begin = int(P);
+                        fa.p_count = 1;
+                        fa.force_accept = 1;
+                        fa.tsr = h->s_tsr;
+                        fa.H = h->s_H + size_t(row) * N;
+                        fa.H_for_gain = (row == 0) ? nullptr : h->s_H;                      // :242 always row 0
+                        fa.gain = h->s_gain;
+                        fa.htime = h->s_htime + size_t(row) * N;
+                        fa.esf = h->s_esf + size_t(row) * d.MM;
+                        fa.eqg = h->s_eqg;
+                        fa.yscratch = h->s_ysc;
+                        HIP_TRY(launch_rx_sync(d, fa, s));
+                        int t4[4];
+                        HIP_TRY(hipMemcpyAsync(t4, h->s_tsr, sizeof(t4), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(hipStreamSynchronize(s));
+                        h->tsr[0] = t4[0];                                                   // :173-175
+                        h->tsr[1] = t4[1];
+                        h->tsr[2] = t4[2];
+                        detected = 1;
+                        break;                                                               // :219
+                    }
+                }
+            }
+            p0 += cnt;
+            if (win < ofdm_rx::TRIAL_CAP) win *= 2;
+        }
+    }
+
+    // ---------------- Loop B: data demod (:221-248)
+    const int64_t tsr0 = int64_t(h->tsr[0]);
+    int64_t n_pat_loop = (n_unique + SD - 1) / SD;                           // range(n_unique)[::S+D]
+    int64_t p_ok = 0;
+    for (int64_t p = 0; p < n_pat_loop; ++p) {
+        const int64_t ptr = tsr0 + int64_t(S) * L * (p * SD + 1);            // :222
+        if (ptr + N - 1 <= n_in) {                                           // :223
+            if (ptr >= n_in)   // an empty slice: np.fft.fft raises "Invalid number of FFT data points (0)"
+                return fail(OFDM_ERR_SHAPE, "data window of pattern %lld starts past the buffer (the reference raises ValueError)", (long long)p);
+            if (p * SD + D - 1 >= h->cfg.num_ofdm_symb)
+                return fail(OFDM_ERR_INDEX, "est_data_freq has %d rows, pattern %lld needs row %lld (the reference raises IndexError)",
+                            h->cfg.num_ofdm_symb, (long long)p, (long long)(p * SD + D - 1));
+            p_ok = p + 1;
+        }
+    }
+    if (p_ok > 0) {
+        DemodArgs da{};
+        da.iq = h->d_in;
+        da.frame_stride = n_in;
+        da.frame_len = n_in;
+        da.n_frames = 1;
+        da.tsr = h->s_tsr;
+        da.gain = h->s_gain;
+        da.eq = h->d_edf;
+        da.bits = nullptr;
+        da.bits_mode = 0;
+        da.mod = d.bps;
+        da.n_dsym = int(p_ok * D);
+        da.spc = 1;
+        da.chunks_per_frame = da.n_dsym;
+        da.row_stride_pat = SD;
+        da.rows_per_frame = h->cfg.num_ofdm_symb;
+        da.zero_skipped = 0;
+        HIP_TRY(launch_rx_demod(d, da, s));
+    }
+
+    // ---------------- output packing (:249-262)
+    const int rows = h->cfg.num_ofdm_symb;
+    int n_del = 0;
+    for (int r = 3; r < rows; r += SD) ++n_del;                              // :249 (literal 3)
+    const int64_t kept = rows - n_del;
+    if (kept * Kd != n_data_symb * Kd)                                       // :255 reshape
+        return fail(OFDM_ERR_SHAPE, "cannot reshape %lld kept rows x %d bins into (1, %lld) (the reference raises ValueError)",
+                    (long long)kept, Kd, (long long)(n_data_symb * Kd));
+    if (h->count > 0) {                                                      // :257
+        if (n_data_symb * Kd > n_out)
+            return fail(OFDM_ERR_SHAPE, "output buffer holds %lld items, need %lld (the reference raises ValueError)",
+                        (long long)n_out, (long long)(n_data_symb * Kd));
+        std::vector<cf> host(size_t(rows) * Kd);
+        HIP_TRY(hipMemcpyAsync(host.data(), h->d_edf, host.size() * sizeof(cf), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        cf* o = reinterpret_cast<cf*>(h_out);
+        int64_t w = 0;
+        for (int r = 0; r < rows; ++r) {
+            if (r >= 3 && (r - 3) % SD == 0) continue;
+            std::memcpy(o + w * Kd, host.data() + size_t(r) * Kd, size_t(Kd) * sizeof(cf));
+            ++w;
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    h->count += 1;                                                           // :260
+    h->corr_obs = 0;                                                         // :261
+    if (rep) {
+        rep->time_synch_ref[0] = h->tsr[0];
+        rep->time_synch_ref[1] = h->tsr[1];
+        rep->time_synch_ref[2] = h->tsr[2];
+        rep->detected = detected;
+        rep->trials_run = trials_run;
+        rep->count = h->count;
+        rep->corr_obs = h->corr_obs;
+        rep->n_data_items = n_data_symb * Kd;
+    }
+    return n_out;                                                            // :262
+}
+
+int ofdm_demap(ofdm_rx* h, const float* d_sym, int64_t n, int32_t modulation, uint8_t* d_hard, float* d_soft0,
+               float* d_soft1, void* stream) {
+    if (!h || (!d_sym && n > 0) || n < 0) return fail(OFDM_ERR_INVALID, "ofdm_demap: bad argument");
+    if (modulation != 1 && modulation != 2 && modulation != 4 && modulation != 6)
+        return fail(OFDM_ERR_INVALID, "modulation must be 1, 2, 4 or 6 bits per symbol");
+    if ((d_soft0 || d_soft1) && modulation != 2)
+        return fail(OFDM_ERR_INVALID, "soft metrics follow BitRecovery.py (QPSK only)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    DemapArgs a{};
+    a.sym = reinterpret_cast<const cf*>(d_sym);
+    a.n = n;
+    a.mod = modulation;
+    a.hard = d_hard;
+    a.soft0 = d_soft0;
+    a.soft1 = d_soft1;
+    a.partial = h->d_partial;
+    HIP_TRY(launch_demap(a, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TX
+int ofdm_tx_destroy(ofdm_tx* h) {
+    if (!h) return OFDM_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->d_tw) hipFree(h->d_tw);
+    if (h->d_zc) hipFree(h->d_zc);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return OFDM_OK;
+}
+
+int ofdm_tx_create(const ofdm_tx_cfg* c, ofdm_tx** out) {
+    if (!c || !out) return fail(OFDM_ERR_INVALID, "ofdm_tx_create: null argument");
+    *out = nullptr;
+    if (!supported_nfft(c->nfft)) return fail(OFDM_ERR_INVALID, "nfft=%d unsupported (64,128,...,4096)", c->nfft);
+    if (c->cp_len < 0 || c->cp_len >= c->nfft) return fail(OFDM_ERR_INVALID, "cp_len=%d out of range", c->cp_len);
+    if (c->num_synch_bins < 2 || c->num_synch_bins > c->nfft || (c->num_synch_bins & 1) || c->num_data_bins < 2 ||
+        c->num_data_bins > c->nfft || (c->num_data_bins & 1))
+        return fail(OFDM_ERR_INVALID, "bin counts must be even and in [2, nfft]");
+    if (c->synch_S < 1 || c->synch_D < 1) return fail(OFDM_ERR_INVALID, "synch_dat must be [>=1, >=1]");
+    if (c->modulation != 1 && c->modulation != 2 && c->modulation != 4 && c->modulation != 6)
+        return fail(OFDM_ERR_INVALID, "modulation must be 1, 2, 4 or 6 bits per symbol");
+    HIP_TRY(hipSetDevice(c->device));
+    ofdm_tx* h = new (std::nothrow) ofdm_tx();
+    if (!h) return fail(OFDM_ERR_NOMEM, "out of host memory");
+    h->cfg = *c;
+    const int N = c->nfft, MM = c->synch_S * c->num_synch_bins;
+    auto tw = make_twiddles(N);
+    auto zc = make_zc(MM, c->zc_root ? c->zc_root : 23, MM);
+    int rc = OFDM_OK;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(OFDM_ERR_HIP, "hipStreamCreate failed");
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM));
+    if (rc == OFDM_OK &&
+        (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess ||
+         hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess))
+        rc = fail(OFDM_ERR_HIP, "device table initialisation failed");
+    if (rc != OFDM_OK) {
+        std::string keep = g_last_error;
+        ofdm_tx_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    TxDev& d = h->dev;
+    d.nfft = N;
+    d.cp = c->cp_len;
+    d.L = N + c->cp_len;
+    d.Ks = c->num_synch_bins;
+    d.Kd = c->num_data_bins;
+    d.S = c->synch_S;
+    d.D = c->synch_D;
+    d.bps = c->modulation;
+    d.tw = h->d_tw;
+    d.zc = h->d_zc;
+    *out = h;
+    return OFDM_OK;
+}
+
+int ofdm_tx_modulate_frames(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode, int64_t n_frames, int32_t n_sym,
+                            float* d_iq, int64_t frame_stride, void* stream) {
+    if (!h || !d_iq || n_frames < 0 || n_sym < 0) return fail(OFDM_ERR_INVALID, "ofdm_tx_modulate_frames: bad argument");
+    if (bits_mode != OFDM_BITS_PACKED && bits_mode != OFDM_BITS_UNPACKED)
+        return fail(OFDM_ERR_INVALID, "bits_mode must be OFDM_BITS_PACKED or OFDM_BITS_UNPACKED");
+    const TxDev& d = h->dev;
+    if (frame_stride < int64_t(n_sym) * d.L) return fail(OFDM_ERR_INVALID, "frame_stride shorter than n_sym*(nfft+cp)");
+    if (n_frames * int64_t(n_sym) > INT32_MAX) return fail(OFDM_ERR_INVALID, "batch too large");
+    const int SD = d.S + d.D;
+    int64_t n_data = int64_t(n_sym / SD) * d.D;
+    const int rem = n_sym % SD;
+    if (rem > d.S) n_data += rem - d.S;
+    const int64_t bits_per_frame = n_data * d.Kd * d.bps;
+    if (bits_mode == OFDM_BITS_PACKED && (bits_per_frame & 7))
+        return fail(OFDM_ERR_INVALID, "packed bits need a whole number of bytes per frame");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    ModArgs a{};
+    a.bits = d_bits;
+    a.bits_mode = bits_mode;
+    a.bits_stride = bits_mode == OFDM_BITS_PACKED ? bits_per_frame / 8 : bits_per_frame;
+    a.n_frames = int(n_frames);
+    a.n_sym = n_sym;
+    a.iq = reinterpret_cast<cf*>(d_iq);
+    a.frame_stride = frame_stride;
+    HIP_TRY(launch_tx_modulate(d, a, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+int ofdm_channel_apply(ofdm_tx* h, const float* d_in, int64_t n_frames, int64_t in_stride, int64_t in_len,
+                       const float* d_taps, int32_t n_taps, int32_t per_frame_taps, float noise_var, uint64_t seed,
+                       float* d_out, int64_t out_stride, int64_t out_len, void* stream) {
+    if (!h || !d_in || !d_out || !d_taps || n_taps < 1 || n_frames < 0 || in_len < 0 || out_len < 0 || noise_var < 0.f)
+        return fail(OFDM_ERR_INVALID, "ofdm_channel_apply: bad argument");
+    if (out_len > in_len + n_taps - 1) return fail(OFDM_ERR_INVALID, "out_len exceeds the convolution length");
+    if (in_stride < in_len || out_stride < out_len) return fail(OFDM_ERR_INVALID, "stride shorter than length");
+    if (n_frames > 65535) return fail(OFDM_ERR_INVALID, "at most 65535 frames per call");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    ChanArgs a{};
+    a.in = reinterpret_cast<const cf*>(d_in);
+    a.in_stride = in_stride;
+    a.in_len = in_len;
+    a.n_frames = int(n_frames);
+    a.taps = reinterpret_cast<const cf*>(d_taps);
+    a.n_taps = n_taps;
+    a.per_frame_taps = per_frame_taps;
+    a.noise_std = std::sqrt(noise_var / 2.f);
+    a.seed = seed;
+    a.out = reinterpret_cast<cf*>(d_out);
+    a.out_stride = out_stride;
+    a.out_len = out_len;
+    HIP_TRY(launch_channel(a, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+}  // extern "C"

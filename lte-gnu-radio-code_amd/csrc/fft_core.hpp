@@ -1,0 +1,204 @@
+// fft_core.hpp -- register/LDS FFT building blocks for gfx950 (MI355X), N = 64 .. 4096.
+//
+// One OFDM symbol is transformed by T = N/P cooperating lanes, each holding P complex points in
+// VGPRs (P = 16, or 8 for N = 64).  N is factored R0 x R1 [x r]; every pass is a register-resident
+// radix-R DIF butterfly, passes are separated by an LDS exchange whose layouts are padded so that
+// both the ds_write_b64 side (16-lane groups, 32 banks) and the ds_read_b64 side (32-lane groups,
+// 64 banks) are conflict-free (MI355X_MICROARCH.md, LDS table):
+//
+//   3-pass  N = 16*16*r, T = 16r          (512, 1024, 2048, 4096)
+//     pass0  lane t=(n1,n2)   : x[t + T*n0]            -> LDS A[k0*(T+2) + t]           * W_N^(k0*t)
+//     pass1  lane t'=n2*16+k0 : A[k0*(T+2)+n1*r+n2]    -> LDS B[(k1*16+k0)*(r+1) + n2]  * W_N^(16*k1*n2)
+//     pass2  lane t''         : B[c*(r+1)+n2], c=t''+T*j -> X[k = c + 256*k2]
+//   2-pass  N = R0*r, T = r                (64, 128, 256)
+//     pass0  lane t=n1        : x[t + T*n0]            -> LDS B[k0*(r+1) + t]           * W_N^(k0*t)
+//     pass1  lane t''         : B[c*(r+1)+n1], c=t''+T*j -> X[k = c + R0*k1]
+//
+// Final bins land in registers as  X[c + NC*kl]  with c = lane + T*j  (NC = N/r): consecutive
+// lanes hold consecutive bins, which is what the coalesced bin de-map needs.
+//
+// Everything here is __host__ __device__ so tests/host/fft_core_host_test.cpp can run the exact
+// index logic lane-by-lane on the CPU (hipcc host compilation; no GPU, no shim macros).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define OFDM_HD __host__ __device__ __forceinline__
+
+namespace ofdm {
+
+struct alignas(8) cf {
+    float x, y;
+};
+
+OFDM_HD cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+OFDM_HD cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+OFDM_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+OFDM_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a*conj(b)
+OFDM_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
+OFDM_HD cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
+OFDM_HD float cnorm2(cf a) { return a.x * a.x + a.y * a.y; }
+
+// cos/sin(2*pi*j/16), j = 0..7
+constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                             0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+constexpr float kSin16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                             1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+
+// d * exp(-2*pi*i*J/R), J in [0, R/2), R in {2,4,8,16}
+template <int R, int J>
+OFDM_HD cf mul_w(cf d) {
+    static_assert(R <= 16 && J < R / 2 + (R == 1), "radix");
+    if constexpr (J == 0) {
+        return d;
+    } else if constexpr (4 * J == R) {
+        return cf{d.y, -d.x};
+    } else if constexpr (8 * J == R) {
+        constexpr float c = 0.70710678118654752f;
+        return cf{(d.x + d.y) * c, (d.y - d.x) * c};
+    } else if constexpr (8 * J == 3 * R) {
+        constexpr float c = 0.70710678118654752f;
+        return cf{(d.y - d.x) * c, -(d.x + d.y) * c};
+    } else {
+        constexpr float c = kCos16[J * (16 / R)];
+        constexpr float s = kSin16[J * (16 / R)];
+        return cf{d.x * c + d.y * s, d.y * c - d.x * s};
+    }
+}
+
+constexpr int bitrev(int k, int R) {
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1) {
+        r = (r << 1) | (k & 1);
+        k >>= 1;
+    }
+    return r;
+}
+
+template <int R, int B, int S, int P, int J>
+OFDM_HD void dif_stage(cf (&v)[P]) {
+    if constexpr (J < R / 2) {
+        const cf a = v[B + S * J];
+        const cf b = v[B + S * (J + R / 2)];
+        v[B + S * J] = a + b;
+        v[B + S * (J + R / 2)] = mul_w<R, J>(a - b);
+        dif_stage<R, B, S, P, J + 1>(v);
+    }
+}
+
+// In-place radix-2 DIF DFT (forward, e^{-i..}) of the R points v[B + S*j]; X[k] ends at v[B + S*bitrev(k,R)].
+template <int R, int B, int S, int P>
+OFDM_HD void dft_dif(cf (&v)[P]) {
+    if constexpr (R > 1) {
+        dif_stage<R, B, S, P, 0>(v);
+        dft_dif<R / 2, B, S, P>(v);
+        dft_dif<R / 2, B + S * (R / 2), S, P>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ plans
+template <int N>
+struct Plan {
+    static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096,
+                  "supported FFT sizes: 64..4096");
+    static constexpr int P = (N == 64) ? 8 : 16;          // points per lane
+    static constexpr int T = N / P;                        // lanes per symbol
+    static constexpr int R0 = P;                           // first radix
+    static constexpr bool THREE = (N >= 512);              // 16 x 16 x r
+    static constexpr int RL = THREE ? N / 256 : N / R0;    // last radix r
+    static constexpr int C = P / RL;                       // last-pass DFTs per lane
+    static constexpr int NC = N / RL;                      // bins k = c + NC*kl
+    static constexpr int LDS_A = THREE ? 16 * (T + 2) : 0;  // exchange A elements
+    static constexpr int LDS_B = NC * (RL + 1);             // exchange B elements
+    static constexpr int LDS_ELEMS = (LDS_A > LDS_B ? LDS_A : LDS_B) > N ? (LDS_A > LDS_B ? LDS_A : LDS_B) : N;
+    static constexpr int SLOTS = (T >= 64) ? 1 : 64 / T;   // symbols handled side by side in one workgroup
+    static constexpr int WG = T * SLOTS;                   // workgroup size (>= 64)
+};
+
+// twiddle table: tw[j] = exp(-2*pi*i*j/N), j in [0,N)
+// Pass-0 twiddles W_N^(k0*t) are lane-specific and stay in VGPRs for the lane's lifetime.
+// Pass-1 twiddles W_N^(16*k1*n2) depend only on (n2 = lane>>4, k1): they live in a small shared
+// table w1tab[n2*16 + k1] (r*16 entries, LDS on the device) instead of 30 more VGPRs per lane.
+template <int N>
+struct LaneTwiddles {
+    cf w0[Plan<N>::R0];   // indexed by k0 (entry 0 unused: it is 1)
+};
+
+template <int N>
+OFDM_HD void load_twiddles(LaneTwiddles<N>& tw, const cf* __restrict__ table, int t) {
+    using PL = Plan<N>;
+#pragma unroll
+    for (int k0 = 0; k0 < PL::R0; ++k0) tw.w0[k0] = table[(k0 * t) & (N - 1)];
+}
+
+// entry e = n2*16 + k1 of the pass-1 table (3-pass plans: e < 16*RL)
+template <int N>
+OFDM_HD cf w1_entry(const cf* __restrict__ table, int e) {
+    return table[(16 * (e & 15) * (e >> 4)) & (N - 1)];
+}
+
+// ------------------------------------------------------------------------------------------ passes
+// Each function is the work of ONE lane t (0..T-1) of one symbol; `lds` is that symbol's exchange
+// region (Plan<N>::LDS_ELEMS elements).  The caller puts a workgroup barrier between consecutive calls.
+
+// pass 0: v[n0] = x[t + T*n0] on entry.
+template <int N>
+OFDM_HD void fft_pass0_store(cf (&v)[Plan<N>::P], cf* lds, const LaneTwiddles<N>& tw, int t) {
+    using PL = Plan<N>;
+    dft_dif<PL::R0, 0, 1, PL::P>(v);
+    constexpr int row = PL::THREE ? (PL::T + 2) : (PL::RL + 1);
+#pragma unroll
+    for (int k0 = 0; k0 < PL::R0; ++k0) {
+        const cf val = v[bitrev(k0, PL::R0)];
+        lds[k0 * row + t] = (k0 == 0) ? val : cmul(val, tw.w0[k0]);
+    }
+}
+
+// pass 1 (3-pass plans): lane t' = n2*16 + k0
+template <int N>
+OFDM_HD void fft_pass1_load(cf (&v)[Plan<N>::P], const cf* lds, int t) {
+    using PL = Plan<N>;
+    const int n2 = t >> 4, k0 = t & 15;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds[k0 * (PL::T + 2) + n1 * PL::RL + n2];
+}
+
+template <int N>
+OFDM_HD void fft_pass1_store(cf (&v)[Plan<N>::P], cf* lds, const cf* w1tab, int t) {
+    using PL = Plan<N>;
+    const int n2 = t >> 4, k0 = t & 15;
+    dft_dif<16, 0, 1, PL::P>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        const cf val = v[bitrev(k1, 16)];
+        lds[(k1 * 16 + k0) * (PL::RL + 1) + n2] = (k1 == 0) ? val : cmul(val, w1tab[n2 * 16 + k1]);
+    }
+}
+
+// last pass: loads, transforms; afterwards bin k = (t + T*j) + NC*kl sits in v[j*RL + bitrev(kl,RL)].
+template <int N>
+OFDM_HD void fft_last_load(cf (&v)[Plan<N>::P], const cf* lds, int t) {
+    using PL = Plan<N>;
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+        const int c = t + PL::T * j;
+#pragma unroll
+        for (int n = 0; n < PL::RL; ++n) v[j * PL::RL + n] = lds[c * (PL::RL + 1) + n];
+    }
+}
+
+template <int N, int J = 0>
+OFDM_HD void fft_last_dft(cf (&v)[Plan<N>::P]) {
+    using PL = Plan<N>;
+    if constexpr (J < PL::C) {
+        dft_dif<PL::RL, J * PL::RL, 1, PL::P>(v);
+        fft_last_dft<N, J + 1>(v);
+    }
+}
+
+// register slot of bin (j, kl) after the last pass
+template <int N>
+constexpr int out_slot(int j, int kl) {
+    return j * Plan<N>::RL + bitrev(kl, Plan<N>::RL);
+}
+
+}  // namespace ofdm

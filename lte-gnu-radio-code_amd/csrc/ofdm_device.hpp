@@ -1,0 +1,142 @@
+// ofdm_device.hpp -- shared device-side helpers: workgroup FFT driver, bin membership, reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft_core.hpp"
+
+namespace ofdm {
+
+// Numerology + constants shared by the RX kernels (passed by value).
+struct RxDev {
+    int nfft, cp, L;          // L = nfft + cp  (rx_b_len)
+    int Ks, Kd;               // sync / data bin counts (even)
+    int S, D;                 // synch_dat
+    int MM;                   // S*Ks
+    int stride;               // sync search stride
+    float gate_mm;            // gate * MM
+    float inv_ls;             // 1 / (S * (1 + 1/snr_ls))
+    float inv_snr_data;       // 1 / snr_data
+    float inv_snr_eqsync;     // 1 / snr_eqsync
+    int bps;                  // bits per symbol of the fused de-mapper
+    const cf* tw;             // [nfft]  exp(-2 pi i j / nfft)
+    const cf* zc;             // [MM]    Zadoff-Chu reference
+};
+
+// Bin list of the reference: i -> k  for  binsP(K) = ([-K/2..-1, 1..K/2] + N) % N  (SynchAndChanEst.py:38-41).
+// The inverse k -> i has a "negative half" and a "positive half"; they overlap only for K == N at k = N/2.
+__device__ __forceinline__ bool bin_neg(int k, int K, int N, int& i) {
+    i = k - (N - (K >> 1));
+    return k >= N - (K >> 1);
+}
+__device__ __forceinline__ bool bin_pos(int k, int K, int& i) {
+    i = (K >> 1) + k - 1;
+    return k >= 1 && k <= (K >> 1);
+}
+
+// ------------------------------------------------------------------------------ reductions over the T lanes of a symbol
+template <int T>
+__device__ __forceinline__ float lanes_sum(float v) {
+    constexpr int W = T < 64 ? T : 64;
+#pragma unroll
+    for (int m = W >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// workgroup barrier (also orders LDS accesses)
+__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+
+// Sum over all T lanes of one symbol.  `red` = 8 floats of LDS scratch per symbol slot (only used when T > 64).
+// Contains one workgroup barrier when T > 64 (all lanes of the workgroup must call it).
+template <int T>
+__device__ __forceinline__ float symbol_sum(float v, float* red, int t) {
+    v = lanes_sum<T>(v);
+    if constexpr (T > 64) {
+        constexpr int NW = T / 64;
+        if ((t & 63) == 0) red[t >> 6] = v;
+        wg_barrier();
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w];
+        return s;
+    } else {
+        return v;
+    }
+}
+
+// arg-max with first-index tie-break over the T lanes of one symbol (idx < 0 means "no candidate")
+template <int T>
+__device__ __forceinline__ void symbol_argmax(float& val, int& idx, float* redv, int* redi, int t) {
+    constexpr int W = T < 64 ? T : 64;
+#pragma unroll
+    for (int m = W >> 1; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(val, m, 64);
+        const int oi = __shfl_xor(idx, m, 64);
+        const bool take = (oi >= 0) && (idx < 0 || ov > val || (ov == val && oi < idx));
+        if (take) {
+            val = ov;
+            idx = oi;
+        }
+    }
+    if constexpr (T > 64) {
+        constexpr int NW = T / 64;
+        if ((t & 63) == 0) {
+            redv[t >> 6] = val;
+            redi[t >> 6] = idx;
+        }
+        wg_barrier();
+        val = redv[0];
+        idx = redi[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float ov = redv[w];
+            const int oi = redi[w];
+            const bool take = (oi >= 0) && (idx < 0 || ov > val || (ov == val && oi < idx));
+            if (take) {
+                val = ov;
+                idx = oi;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ workgroup LDS carve
+// [ SLOTS x ( exchange/staging region | 16 dwords reduction scratch ) | pass-1 twiddle table ]
+template <int N>
+struct WgLds {
+    static constexpr int ELEMS = Plan<N>::LDS_ELEMS + (Plan<N>::LDS_ELEMS & 1);
+    static constexpr int RED_CF = 8;                                  // 8 cf = 16 dwords of scratch
+    static constexpr int STRIDE = ELEMS + RED_CF;                     // cf units, even -> 16 B aligned
+    static constexpr int W1_ELEMS = Plan<N>::THREE ? 16 * Plan<N>::RL : 0;
+    static constexpr size_t BYTES = (size_t(STRIDE) * Plan<N>::SLOTS + W1_ELEMS) * sizeof(cf);
+};
+
+// fills the workgroup's pass-1 twiddle table; the caller's first barrier (inside wg_fft) publishes it
+template <int N>
+__device__ __forceinline__ const cf* wg_init_w1(cf* smem, const cf* __restrict__ table, int tid) {
+    cf* w1 = smem + WgLds<N>::STRIDE * Plan<N>::SLOTS;
+    if constexpr (Plan<N>::THREE) {
+        if (tid < WgLds<N>::W1_ELEMS) w1[tid] = w1_entry<N>(table, tid);
+    }
+    return w1;
+}
+
+// ------------------------------------------------------------------------------ workgroup FFT
+// Forward N-point FFT of one symbol held as v[n0] = x[t + T*n0] across its T lanes.
+// On return lane t holds bin k = (t + T*j) + NC*kl in v[out_slot<N>(j,kl)].
+// Contains 1 (2-pass) or 3 (3-pass) workgroup barriers; the symbol's LDS region may still be read by
+// other lanes on return, so the caller must barrier before overwriting it.
+template <int N>
+__device__ __forceinline__ void wg_fft(cf (&v)[Plan<N>::P], cf* lds, const LaneTwiddles<N>& tw, const cf* w1tab, int t) {
+    fft_pass0_store<N>(v, lds, tw, t);
+    wg_barrier();
+    if constexpr (Plan<N>::THREE) {
+        fft_pass1_load<N>(v, lds, t);
+        wg_barrier();
+        fft_pass1_store<N>(v, lds, w1tab, t);
+        wg_barrier();
+    }
+    fft_last_load<N>(v, lds, t);
+    fft_last_dft<N>(v);
+}
+
+}  // namespace ofdm

@@ -1,0 +1,97 @@
+// ofdm_launch.hpp -- host-visible argument structs + launch wrappers of the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ofdm_device.hpp"
+
+namespace ofdm {
+
+// ---- RX data demod (reference: SynchAndChanEst.py:221-248, "Loop B") --------------------------
+struct DemodArgs {
+    const cf* iq;            // frames, frame f at iq + f*frame_stride
+    int64_t frame_stride;
+    int64_t frame_len;       // valid samples per frame (windows past the end read zeros, like fft(x, N))
+    int n_frames;
+    const int* tsr;          // [n_frames][4]  {time_synch_ref[0], lag, int(max), detected}
+    const cf* gain;          // [n_frames][Kd] conj(H)/(|H|^2+1/snr) * exp(j 2pi lag k/N)
+    cf* eq;                  // [n_frames][rows_per_frame][Kd] or null
+    uint8_t* bits;           // hard bits or null
+    int bits_mode;           // ofdm_bits_mode
+    int mod;                 // bits per symbol of the de-mapper (1,2,4,6)
+    int n_dsym;              // data symbols visited per frame (= n_pat * D)
+    int spc;                 // data symbols per chunk (one chunk = one symbol slot's loop)
+    int chunks_per_frame;
+    int row_stride_pat;      // output row = p*row_stride_pat + n   (S+D in stream mode, D in batch mode)
+    int rows_per_frame;
+    int zero_skipped;        // write zeros for patterns whose guard fails (batch mode)
+};
+
+// ---- RX sync search + LS estimate (reference: SynchAndChanEst.py:143-219, "Loop A") -----------
+struct SyncArgs {
+    const cf* iq;
+    int64_t frame_stride;
+    int64_t frame_len;
+    int n_frames;
+    int mode;                // 0: per-frame sequential search + finalize; 1: trial table only (frame 0)
+    int p_begin;
+    int p_count;             // mode 0: max trials (<=0: unbounded); mode 1: number of trials in the table
+    int force_accept;        // mode 0: accept trial p_begin regardless of the gate (host already decided)
+    int* tsr;                // [n_frames][4]
+    cf* H;                   // [n_frames][N]   est_chan_freq_P row
+    const cf* H_for_gain;    // stream block, calls after the first: the data equaliser keeps using row 0 (:242); null = use H
+    cf* gain;                // [n_frames][Kd]
+    cf* htime;               // [n_frames][N]   est_chan_time row, or null
+    cf* esf;                 // [n_frames][MM]  est_synch_freq row, or null
+    cf* eqg;                 // [n_frames][Ks]  eq_gain, or null
+    cf* yscratch;            // [n_frames][MM]  raw sync-bin values of the current trial (needed for esf), or null
+    float* trial_m;          // mode 1: [p_count] max|corr| (-1 = trial not valid)
+    int* trial_d;            // mode 1: [p_count] argmax lag
+};
+
+struct DemapArgs {
+    const cf* sym;
+    int64_t n;
+    int mod;
+    uint8_t* hard;           // n*bps bytes or null
+    float* soft0;            // n*bps or null (QPSK)
+    float* soft1;
+    double* partial;         // [DEMAP_PARTIALS] scratch for the dmin mean
+};
+constexpr int DEMAP_PARTIALS = 256;
+
+// ---- TX (reference: MultiAntennaSystem.py:113-218) ---------------------------------------------
+struct TxDev {
+    int nfft, cp, L, Ks, Kd, S, D, bps;
+    const cf* tw;
+    const cf* zc;            // [S*Ks]
+};
+struct ModArgs {
+    const uint8_t* bits;
+    int bits_mode;
+    int64_t bits_stride;     // bytes per frame in `bits`
+    int n_frames;
+    int n_sym;               // symbols per frame
+    cf* iq;
+    int64_t frame_stride;
+};
+struct ChanArgs {
+    const cf* in;
+    int64_t in_stride, in_len;
+    int n_frames;
+    const cf* taps;
+    int n_taps;
+    int per_frame_taps;
+    float noise_std;         // per real component: sqrt(noise_var/2)
+    uint64_t seed;
+    cf* out;
+    int64_t out_stride, out_len;
+};
+
+hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s);
+hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s);
+hipError_t launch_demap(const DemapArgs& a, hipStream_t s);
+hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s);
+hipError_t launch_channel(const ChanArgs& a, hipStream_t s);
+size_t rx_lds_bytes(int nfft);
+
+}  // namespace ofdm

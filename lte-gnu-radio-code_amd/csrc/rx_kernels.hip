@@ -1,0 +1,575 @@
+// rx_kernels.hip -- gfx950 kernels of the OFDM receive path.
+//
+//   rx_sync_kernel   Zadoff-Chu lag-correlation timing search + LS channel estimate + equaliser gains
+//                    (reference: gr-utsa_ofdm/python/SynchAndChanEst.py:143-219)
+//   rx_demod_kernel  CP strip + N-point FFT + data-bin de-map + per-symbol power normalisation +
+//                    lag de-rotation + one-tap MMSE equalise (+ fused hard de-map)   (:221-248)
+//   demap kernels    BitRecovery hard / max-log soft outputs (LEGACY/gr-ofdm-rx/python/BitRecovery.py:66-157)
+//
+// Layout: one OFDM symbol is owned by T = N/16 lanes (fft_core.hpp); a workgroup holds max(T,64)
+// lanes = SLOTS symbols side by side.  A symbol is read from HBM exactly once (coalesced, CP skipped
+// by offset), lives in VGPRs/LDS through the FFT, and leaves as one coalesced 16 B/lane store of
+// its Kd equalised bins (+ packed bits).  No MFMA: the path is FFT + elementwise, HBM-bound.
+#include "ofdm_launch.hpp"
+
+namespace ofdm {
+
+// ------------------------------------------------------------------------------------------ de-map
+// BitRecovery's hard decision for float32 inputs (see oracle/ofdm_oracle.py:demap_hard for the derivation):
+//   QPSK  b = 1  iff  -sqrt2 <= x < 0  or  x > sqrt2      (sign rule + the reference's outlier flip)
+__device__ __forceinline__ unsigned qpsk_axis_bit(float x) {
+    constexpr float t = 1.41421354f;   // largest float32 below sqrt(2)
+    return ((x < 0.f) & (x >= -t)) | (x > t);
+}
+
+// returns the symbol's bits, b0 in the most significant of `bps` bits
+__device__ __forceinline__ unsigned hard_bits(cf z, int bps) {
+    if (bps == 2) return (qpsk_axis_bit(z.x) << 1) | qpsk_axis_bit(z.y);
+    if (bps == 1) return z.x > 0.f;
+    if (bps == 4) {
+        constexpr float t = 0.63245553203367588f;   // 2/sqrt(10)
+        return ((z.x < 0.f) << 3) | ((z.y < 0.f) << 2) | ((fabsf(z.x) > t) << 1) | (fabsf(z.y) > t);
+    }
+    constexpr float a = 0.61721339984836765f;        // 4/sqrt(42)
+    constexpr float c = 0.30860669992418382f;        // 2/sqrt(42)
+    return ((z.x < 0.f) << 5) | ((z.y < 0.f) << 4) | ((fabsf(z.x) > a) << 3) | ((fabsf(z.y) > a) << 2) |
+           ((fabsf(fabsf(z.x) - a) > c) << 1) | (fabsf(fabsf(z.y) - a) > c);
+}
+
+// ------------------------------------------------------------------------------------------ data demod
+// list position i (0..Kd-1) of the reference's bins_used_P  ->  FFT bin k
+__device__ __forceinline__ int list_to_bin(int i, int K, int N) { return (i < (K >> 1)) ? N - (K >> 1) + i : i - (K >> 1) + 1; }
+
+// GREG: keep the lane's equaliser gains in VGPRs across the symbol loop (32 VGPRs) instead of
+// re-reading them (L2-resident, coalesced 16 B/lane) for every symbol.
+template <int N, bool GREG>
+__global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, DemodArgs a) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P, Q = P / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
+
+    const int64_t chunk = int64_t(blockIdx.x) * PL::SLOTS + slot;
+    const int64_t total_chunks = int64_t(a.n_frames) * a.chunks_per_frame;
+    const bool active = chunk < total_chunks;
+    const int frame = active ? int(chunk / a.chunks_per_frame) : 0;
+    const int cidx = active ? int(chunk % a.chunks_per_frame) : 0;
+    const int ds0 = cidx * a.spc;
+    const int ds1 = min(ds0 + a.spc, a.n_dsym);
+
+    LaneTwiddles<N> tw;
+    load_twiddles<N>(tw, rx.tw, t);
+
+    const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
+    const int tsr0 = active ? a.tsr[frame * 4 + 0] : 0;
+    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
+
+    // equaliser gains of this lane's output positions (4 consecutive list entries per q), fixed for the chunk
+    const cf* gain = a.gain + int64_t(frame) * Kd;
+    cf g[GREG ? Q : 1][4];
+    if constexpr (GREG) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int idx = 4 * (t + T * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[q][e] = (active && idx + e < Kd) ? gain[idx + e] : cf{0.f, 0.f};
+        }
+    }
+
+    for (int it = 0; it < a.spc; ++it) {
+        const int ds = ds0 + it;
+        const bool sym_valid = active && ds < ds1;
+        const int p = ds / D, n_ = ds - p * D;
+        // SynchAndChanEst.py:222-223  data_ptr = tsr0 + S*L*(P+1), P = p*(S+D); guard once per pattern
+        const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
+        const bool compute = sym_valid && (pat_ptr + N - 1 <= a.frame_len);
+        const int64_t start = pat_ptr + int64_t(L) * n_;            // :226 CP strip by offset
+
+        cf v[P];
+        if (compute && start + N <= a.frame_len) {
+            const cf* src = frame_iq + start + t;
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) v[n0] = src[T * n0];
+        } else {
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) {
+                const int64_t idx = start + t + T * n0;              // short tail: fft(x, N) zero-pads (:230)
+                v[n0] = (compute && idx < a.frame_len) ? frame_iq[idx] : cf{0.f, 0.f};
+            }
+        }
+        wg_fft<N>(v, lds, tw, w1tab, t);                             // :230
+        wg_barrier();                                                // exchange region -> staging region
+
+        // Re-materialise Kd per symbol: keeps hipcc from hoisting the 16 per-slot membership weights and
+        // list offsets (loop-invariant per lane) into ~50 extra VGPRs held across the symbol loop.
+        int Kd_ = Kd;
+        asm volatile("" : "+s"(Kd_));
+        // stage all bins in natural order; accumulate the power of the Kd listed data bins (:232-233)
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+            for (int kl = 0; kl < PL::RL; ++kl) {
+                const int k = (t + T * j) + PL::NC * kl;
+                const cf val = v[out_slot<N>(j, kl)];
+                lds[k] = val;
+                const float w = float(int(k >= N - (Kd_ >> 1)) + int(k >= 1 && k <= (Kd_ >> 1)));   // listed twice iff Kd == N, k == N/2
+                psum += w * cnorm2(val);
+            }
+        }
+        psum = lanes_sum<T>(psum);
+        if constexpr (T > 64) {
+            if ((t & 63) == 0) red[t >> 6] = psum;
+        }
+        wg_barrier();
+        if constexpr (T > 64) {
+            psum = 0.f;
+#pragma unroll
+            for (int w = 0; w < T / 64; ++w) psum += red[w];
+        }
+        const float scale = sqrtf(float(Kd_) / psum);                // :233 p_est0
+
+        const int row = p * a.row_stride_pat + n_;
+        const int64_t orow = int64_t(frame) * a.rows_per_frame + row;
+        if (sym_valid && (compute || a.zero_skipped)) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int idx = 4 * (t + T * q);
+                if (idx < Kd_) {
+                    const bool four = idx + 2 < Kd_;
+                    cf z[4], gq[4];
+                    if constexpr (GREG) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gq[e] = g[q][e];
+                    } else {
+                        const float4 g01 = *reinterpret_cast<const float4*>(gain + idx);
+                        const float4 g23 = four ? *reinterpret_cast<const float4*>(gain + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
+                        gq[0] = cf{g01.x, g01.y};
+                        gq[1] = cf{g01.z, g01.w};
+                        gq[2] = cf{g23.x, g23.y};
+                        gq[3] = cf{g23.z, g23.w};
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                    // :232 bin-list order, :235-248 x*p_est0 * e^{j..} * gain
+                        const cf x = lds[list_to_bin(min(idx + e, Kd_ - 1), Kd_, N)];
+                        z[e] = compute ? cmul(cscale(x, scale), gq[e]) : cf{0.f, 0.f};
+                    }
+                    if (a.eq) {
+                        float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd + idx);
+                        o[0] = float4{z[0].x, z[0].y, z[1].x, z[1].y};
+                        if (four) o[1] = float4{z[2].x, z[2].y, z[3].x, z[3].y};
+                    }
+                    if (a.bits) {
+                        unsigned hb[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hb[e] = hard_bits(z[e], a.mod);
+                        if (a.bits_mode == 1) {                      // packed MSB-first: 4 symbols -> mod/2 bytes
+                            const unsigned w = (((((hb[0] << a.mod) | hb[1]) << a.mod) | hb[2]) << a.mod) | hb[3];
+                            uint8_t* o = a.bits + (orow * Kd + idx) * a.mod / 8;
+                            if (a.mod == 2) {
+                                o[0] = uint8_t(w);
+                            } else if (a.mod == 4) {
+                                *reinterpret_cast<uint16_t*>(o) = uint16_t(((w & 0xffu) << 8) | (w >> 8));
+                            } else {
+                                o[0] = uint8_t(w >> 16);
+                                o[1] = uint8_t(w >> 8);
+                                o[2] = uint8_t(w);
+                            }
+                        } else {                                     // one bit per byte
+                            uint8_t* o = a.bits + (orow * Kd + idx) * a.mod;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (e < 2 || four) {
+#pragma unroll
+                                    for (int b = 0; b < 6; ++b)
+                                        if (b < a.mod) o[e * a.mod + b] = uint8_t((hb[e] >> (a.mod - 1 - b)) & 1u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        wg_barrier();                                                // staging region free for the next symbol
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sync
+// One sync trial P of one frame (SynchAndChanEst.py:145-164).  On return: Z (per-lane bins, register
+// slot order) = sum over the S sync symbols of Y[k]*conj(zc), zdup = negative-half part of a bin that
+// is listed twice (K == N only), p_est, m = max|del_mat|, dhat = argmax lag.
+template <int N>
+__device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, int64_t frame_len, bool active,
+                                           int Ptrial, cf* lds, float* red, const LaneTwiddles<N>& tw, const cf* w1tab, int t,
+                                           cf (&Z)[Plan<N>::P], cf& zdup, float& p_est, float& m, int& dhat,
+                                           cf* yscratch) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P;
+    int* redi = reinterpret_cast<int*>(red) + 8;
+#pragma unroll
+    for (int s = 0; s < P; ++s) Z[s] = cf{0.f, 0.f};
+    zdup = cf{0.f, 0.f};
+    float psum = 0.f;
+    for (int LL = 0; LL < rx.S; ++LL) {
+        const int64_t w0 = int64_t(rx.L) * LL + int64_t(Ptrial) * rx.stride + rx.cp;   // :146
+        cf v[P];
+#pragma unroll
+        for (int n0 = 0; n0 < P; ++n0) {
+            const int64_t idx = w0 + t + T * n0;
+            v[n0] = (active && idx < frame_len) ? frame_iq[idx] : cf{0.f, 0.f};
+        }
+        wg_fft<N>(v, lds, tw, w1tab, t);                                                       // :152
+#pragma unroll
+        for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+            for (int kl = 0; kl < PL::RL; ++kl) {
+                const int k = (t + T * j) + PL::NC * kl;
+                const int s = out_slot<N>(j, kl);
+                int in_, ip_;
+                const bool neg = bin_neg(k, rx.Ks, N, in_);
+                const bool pos = bin_pos(k, rx.Ks, ip_);
+                if (neg) {                                                              // :153-161
+                    const cf c = cmulc(v[s], rx.zc[LL * rx.Ks + in_]);
+                    Z[s] = Z[s] + c;
+                    psum += cnorm2(v[s]);
+                    if (pos) zdup = zdup + c;
+                    if (yscratch && active) yscratch[LL * rx.Ks + in_] = v[s];
+                }
+                if (pos) {
+                    const cf c = cmulc(v[s], rx.zc[LL * rx.Ks + ip_]);
+                    Z[s] = Z[s] + c;
+                    psum += cnorm2(v[s]);
+                    if (yscratch && active) yscratch[LL * rx.Ks + ip_] = v[s];
+                }
+            }
+        }
+        wg_barrier();
+    }
+    psum = symbol_sum<T>(psum, red, t);
+    p_est = sqrtf(float(rx.MM) / psum);                                                 // :157
+
+    // del_mat[d] = sum_k e^{+j 2pi d k/N} Z[k]  == unnormalised inverse DFT of Z read at d = 0..cp
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+        for (int kl = 0; kl < PL::RL; ++kl) lds[(t + T * j) + PL::NC * kl] = Z[out_slot<N>(j, kl)];
+    }
+    wg_barrier();
+    cf v[P];
+#pragma unroll
+    for (int n0 = 0; n0 < P; ++n0) v[n0] = cconj(lds[t + T * n0]);
+    wg_barrier();
+    wg_fft<N>(v, lds, tw, w1tab, t);
+    float best = -1.f;
+    int bi = -1;
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+        for (int kl = 0; kl < PL::RL; ++kl) {
+            const int d = (t + T * j) + PL::NC * kl;
+            const float m2 = cnorm2(v[out_slot<N>(j, kl)]);
+            if (d <= rx.cp && (bi < 0 || m2 > best || (m2 == best && d < bi))) {        // :163 first max
+                best = m2;
+                bi = d;
+            }
+        }
+    }
+    symbol_argmax<T>(best, bi, red, redi, t);
+    m = p_est * sqrtf(best);                                                            // :164
+    dhat = bi;
+    wg_barrier();
+}
+
+template <int N>
+__global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs a) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
+
+    LaneTwiddles<N> tw;
+    load_twiddles<N>(tw, rx.tw, t);
+
+    const int64_t unit = int64_t(blockIdx.x) * PL::SLOTS + slot;
+    const int Ks = rx.Ks, Kd = rx.Kd;
+
+    if (a.mode == 1) {
+        // ---- trial table for the stream block: unit = trial index, frame 0
+        const bool active = unit < a.p_count;
+        const int Ptrial = a.p_begin + int(unit);
+        const bool valid = active && (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);  // :144
+        cf Z[P];
+        cf zdup;
+        float p_est, m;
+        int dhat;
+        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr);
+        if (active && t == 0) {
+            a.trial_m[unit] = valid ? m : -1.f;
+            a.trial_d[unit] = valid ? dhat : 0;
+        }
+        return;
+    }
+
+    // ---- mode 0: sequential search per frame (first accepted trial wins, :166-219), then finalize
+    const bool active = unit < a.n_frames;
+    const int frame = active ? int(unit) : 0;
+    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
+    cf* ysc = a.yscratch ? a.yscratch + int64_t(frame) * rx.MM : nullptr;
+
+    bool found = false;
+    cf Zs[P];
+    cf zdups = cf{0.f, 0.f};
+    float pests = 0.f, ms = 0.f;
+    int dhats = 0, Phit = 0;
+#pragma unroll
+    for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
+
+    for (int it = 0;; ++it) {
+        const int Ptrial = a.p_begin + it;
+        const bool valid = active && !found && (a.p_count <= 0 || it < a.p_count) &&
+                           (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+        if (!__syncthreads_or(valid ? 1 : 0)) break;
+        cf Z[P];
+        cf zdup;
+        float p_est, m;
+        int dhat;
+        sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc);
+        if (valid && (a.force_accept || m > rx.gate_mm)) {                              // :166
+            found = true;
+#pragma unroll
+            for (int s = 0; s < P; ++s) Zs[s] = Z[s];
+            zdups = zdup;
+            pests = p_est;
+            ms = m;
+            dhats = dhat;
+            Phit = Ptrial;
+        }
+    }
+
+    // ---- finalize (:171-218): LS estimate on the sync bins, equaliser gains, channel impulse response
+    if (active && t == 0) {
+        int* o = a.tsr + int64_t(frame) * 4;
+        o[0] = found ? Phit * rx.stride + rx.cp : 0;                                    // :173
+        o[1] = found ? dhats : 0;                                                        // :174
+        o[2] = found ? int(ms) : 0;                                                      // :175
+        o[3] = found ? 1 : 0;
+    }
+    cf Hreg[P];
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+        for (int kl = 0; kl < PL::RL; ++kl) {
+            const int k = (t + T * j) + PL::NC * kl;
+            const int s = out_slot<N>(j, kl);
+            int in_, ip_;
+            const bool neg = bin_neg(k, Ks, N, in_);
+            const bool pos = bin_pos(k, Ks, ip_);
+            const cf rot = cconj(rx.tw[(dhats * k) & (N - 1)]);                         // e^{+j 2pi d k/N}  :177
+            const float sc = pests * rx.inv_ls;                                         // p_est / (S (1+1/snr)) :180-184
+            const cf Zn = (pos && neg) ? zdups : Zs[s];
+            const cf Zp = (pos && neg) ? (Zs[s] - zdups) : Zs[s];
+            const cf Hn = cscale(cmul(rot, Zn), sc);
+            const cf Hp = cscale(cmul(rot, Zp), sc);
+            // chan_est1[synch_bins] = chan_est : a bin listed twice keeps its LAST (positive-half) entry :186-188
+            cf Hk = cf{0.f, 0.f};
+            if (found && neg) Hk = Hn;
+            if (found && pos) Hk = Hp;
+            Hreg[s] = Hk;
+            if (active) {
+                a.H[int64_t(frame) * N + k] = Hk;
+                if (a.eqg || a.esf) {
+                    // eq_gain = conj(chan_est)/(|chan_est|^2 + 1/snr) (:213-216); est_synch_freq = eq_gain * r (:217-218)
+                    if (neg) {
+                        const cf e = found ? cscale(cconj(Hn), 1.f / (cnorm2(Hn) + rx.inv_snr_eqsync)) : cf{0.f, 0.f};
+                        if (a.eqg) a.eqg[int64_t(frame) * Ks + in_] = e;
+                        if (a.esf && ysc)
+                            for (int LL = 0; LL < rx.S; ++LL)
+                                a.esf[int64_t(frame) * rx.MM + LL * Ks + in_] =
+                                    found ? cmul(e, cscale(cmul(rot, ysc[LL * Ks + in_]), pests)) : cf{0.f, 0.f};
+                    }
+                    if (pos) {
+                        const cf e = found ? cscale(cconj(Hp), 1.f / (cnorm2(Hp) + rx.inv_snr_eqsync)) : cf{0.f, 0.f};
+                        if (a.eqg) a.eqg[int64_t(frame) * Ks + ip_] = e;
+                        if (a.esf && ysc)
+                            for (int LL = 0; LL < rx.S; ++LL)
+                                a.esf[int64_t(frame) * rx.MM + LL * Ks + ip_] =
+                                    found ? cmul(e, cscale(cmul(rot, ysc[LL * Ks + ip_]), pests)) : cf{0.f, 0.f};
+                    }
+                }
+                // data-bin gain: conj(Hd)/(|Hd|^2 + 1/SNR_lin) (:242-246) folded with the lag de-rotation (:237-240)
+                const cf Hg = a.H_for_gain ? a.H_for_gain[int64_t(frame) * N + k] : Hk;
+                const cf gk = cmul(cscale(cconj(Hg), 1.f / (cnorm2(Hg) + rx.inv_snr_data)), rot);
+                int id_;
+                if (bin_neg(k, Kd, N, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
+                if (bin_pos(k, Kd, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
+            }
+        }
+    }
+    if (a.htime) {                                                                      // :202,212  ifft(chan_est1)
+#pragma unroll
+        for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+            for (int kl = 0; kl < PL::RL; ++kl) lds[(t + T * j) + PL::NC * kl] = Hreg[out_slot<N>(j, kl)];
+        }
+        wg_barrier();
+        cf v[P];
+#pragma unroll
+        for (int n0 = 0; n0 < P; ++n0) v[n0] = cconj(lds[t + T * n0]);
+        wg_barrier();
+        wg_fft<N>(v, lds, tw, w1tab, t);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+                for (int kl = 0; kl < PL::RL; ++kl)
+                    a.htime[int64_t(frame) * N + (t + T * j) + PL::NC * kl] =
+                        cscale(cconj(v[out_slot<N>(j, kl)]), 1.f / float(N));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ standalone de-mapper
+__global__ void demap_hard_kernel(DemapArgs a) {
+    const int64_t n = a.n;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const unsigned hb = hard_bits(a.sym[i], a.mod);
+        for (int b = 0; b < a.mod; ++b) a.hard[i * a.mod + b] = (hb >> (a.mod - 1 - b)) & 1u;
+    }
+}
+
+__device__ __forceinline__ void qpsk_nearest(cf z, bool& re_pos, bool& im_pos, cf& e) {
+    // quadrant tests in the reference's order ++, -+, --, +- (BitRecovery.py:106-125)
+    re_pos = (z.x > 0.f) || (z.x == 0.f && z.y >= 0.f);
+    im_pos = (z.y >= 0.f);
+    constexpr float c = 0.70710678118654752f;
+    e = cf{z.x - (re_pos ? c : -c), z.y - (im_pos ? c : -c)};                            // :93-98
+}
+
+// pass 1: partial sums of dmin (double) -> a.partial[blockIdx]   (BitRecovery.py:88,102)
+__global__ void __launch_bounds__(256) demap_dmin_kernel(DemapArgs a) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+        bool rp, ip;
+        cf e;
+        qpsk_nearest(a.sym[i], rp, ip, e);
+        acc += double(sqrtf(cnorm2(e)));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0];
+}
+
+// pass 2: llrp0 / llrp1 (BitRecovery.py:102-125)
+__global__ void __launch_bounds__(256) demap_soft_kernel(DemapArgs a) {
+    __shared__ double sh_tot;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < DEMAP_PARTIALS; ++i) s += a.partial[i];
+        sh_tot = s;
+    }
+    __syncthreads();
+    const double sigma = 0.7071067811865476 * (sh_tot / double(a.n));                    // :102
+    const float hf = float(-0.5 / (sigma * sigma));                                      // -0.5*dfact :103
+    constexpr float K = 1.414213562373095f;                                              // :57
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+        bool rp, ip;
+        cf e;
+        qpsk_nearest(a.sym[i], rp, ip, e);
+        const float nr = hf * fabsf(e.x), fr = hf * (K - fabsf(e.x));
+        const float ni = hf * fabsf(e.y), fi = hf * (K - fabsf(e.y));
+        if (a.soft0) {
+            a.soft0[2 * i] = rp ? nr : fr;
+            a.soft0[2 * i + 1] = ip ? ni : fi;
+        }
+        if (a.soft1) {
+            a.soft1[2 * i] = rp ? fr : nr;
+            a.soft1[2 * i + 1] = ip ? fi : ni;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+template <int N>
+static hipError_t launch_demod_n(const RxDev& rx, const DemodArgs& a, hipStream_t s) {
+    const int64_t chunks = int64_t(a.n_frames) * a.chunks_per_frame;
+    const unsigned grid = unsigned((chunks + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((rx_demod_kernel<N, false>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
+    return hipGetLastError();
+}
+template <int N>
+static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
+    const int64_t units = (a.mode == 1) ? a.p_count : a.n_frames;
+    const unsigned grid = unsigned((units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(rx_sync_kernel<N>, dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
+    return hipGetLastError();
+}
+
+#define OFDM_DISPATCH_N(nfft, CALL)      \
+    switch (nfft) {                      \
+        case 64: return CALL(64);        \
+        case 128: return CALL(128);      \
+        case 256: return CALL(256);      \
+        case 512: return CALL(512);      \
+        case 1024: return CALL(1024);    \
+        case 2048: return CALL(2048);    \
+        case 4096: return CALL(4096);    \
+        default: return hipErrorInvalidValue; \
+    }
+
+hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s) {
+#define CALL(n) launch_demod_n<n>(rx, a, s)
+    OFDM_DISPATCH_N(rx.nfft, CALL)
+#undef CALL
+}
+hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
+#define CALL(n) launch_sync_n<n>(rx, a, s)
+    OFDM_DISPATCH_N(rx.nfft, CALL)
+#undef CALL
+}
+size_t rx_lds_bytes(int nfft) {
+#define CALL(n) WgLds<n>::BYTES
+    switch (nfft) {
+        case 64: return CALL(64);
+        case 128: return CALL(128);
+        case 256: return CALL(256);
+        case 512: return CALL(512);
+        case 1024: return CALL(1024);
+        case 2048: return CALL(2048);
+        case 4096: return CALL(4096);
+    }
+#undef CALL
+    return 0;
+}
+
+hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 2048));
+    if (a.hard) hipLaunchKernelGGL(demap_hard_kernel, dim3(grid), dim3(256), 0, s, a);
+    if (a.soft0 || a.soft1) {
+        hipLaunchKernelGGL(demap_dmin_kernel, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ofdm

@@ -1,0 +1,216 @@
+// tx_kernels.hip -- gfx950 kernels of the OFDM transmit path and the loop-back channel.
+//
+//   tx_modulate_kernel  bits -> QPSK/QAM symbols -> resource grid (ZC sync symbols) -> IFFT -> CP ->
+//                       per-symbol power normalisation
+//                       (reference: LEGACY/gr-ofdm-rx/python/txrx_mod/MultiAntennaSystem.py:113-218,
+//                        SynchSignal.py:13-30)
+//   channel_kernel      tapped-delay-line convolution + Philox/Box-Muller AWGN  (MultiAntennaSystem.py:221-260)
+#include "ofdm_launch.hpp"
+
+namespace ofdm {
+
+__device__ __forceinline__ unsigned read_bits(const uint8_t* bits, int mode, int64_t bit0, int bps) {
+    unsigned v = 0;
+    if (mode == 2) {
+        for (int b = 0; b < bps; ++b) v = (v << 1) | (bits[bit0 + b] & 1u);
+    } else {
+        for (int b = 0; b < bps; ++b) {
+            const int64_t B = bit0 + b;
+            v = (v << 1) | ((bits[B >> 3] >> (7 - (B & 7))) & 1u);
+        }
+    }
+    return v;
+}
+
+// MultiAntennaSystem.py:156-178 (BPSK, QPSK); 16/64-QAM: 3GPP TS 36.211 7.1 (extension)
+__device__ __forceinline__ cf map_symbol(unsigned v, int bps) {
+    if (bps == 2) {
+        constexpr float c = 0.70710678118654752f;
+        return cf{(v & 2u) ? -c : c, (v & 1u) ? -c : c};
+    }
+    if (bps == 1) return cf{v ? 1.f : -1.f, 0.f};
+    if (bps == 4) {
+        constexpr float s = 0.31622776601683794f;   // 1/sqrt(10)
+        const float si = (v & 8u) ? -1.f : 1.f, sq = (v & 4u) ? -1.f : 1.f;
+        const float ai = (v & 2u) ? 3.f : 1.f, aq = (v & 1u) ? 3.f : 1.f;
+        return cf{si * ai * s, sq * aq * s};
+    }
+    constexpr float s = 0.15430334996209191f;       // 1/sqrt(42)
+    const float si = (v & 32u) ? -1.f : 1.f, sq = (v & 16u) ? -1.f : 1.f;
+    // |I| = 4 - s2*(2 - s4) with s = 1-2b : (b2,b4) -> 3,1,5,7 for 00,01,10,11
+    const float s2i = (v & 8u) ? -1.f : 1.f, s4i = (v & 2u) ? -1.f : 1.f;
+    const float s2q = (v & 4u) ? -1.f : 1.f, s4q = (v & 1u) ? -1.f : 1.f;
+    return cf{si * (4.f - s2i * (2.f - s4i)) * s, sq * (4.f - s2q * (2.f - s4q)) * s};
+}
+
+template <int N>
+__global__ void __launch_bounds__(Plan<N>::WG) tx_modulate_kernel(TxDev tx, ModArgs a) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    const cf* w1tab = wg_init_w1<N>(smem, tx.tw, tid);
+
+    LaneTwiddles<N> tw;
+    load_twiddles<N>(tw, tx.tw, t);
+
+    const int64_t unit = int64_t(blockIdx.x) * PL::SLOTS + slot;
+    const bool active = unit < int64_t(a.n_frames) * a.n_sym;
+    const int frame = active ? int(unit / a.n_sym) : 0;
+    const int sym = active ? int(unit % a.n_sym) : 0;
+    const int SD = tx.S + tx.D;
+    const int pat = sym / SD, r = sym - pat * SD;
+    const bool is_sync = r < tx.S;                                    // symbol_pattern == 0  (:136)
+    const int64_t ds = int64_t(pat) * tx.D + (r - tx.S);              // loop_data (:134,180)
+    const uint8_t* fbits = a.bits ? a.bits + int64_t(frame) * a.bits_stride : nullptr;
+
+    // resource grid row X[n] (:135-183), conjugated: ifft(X) = conj(fft(conj(X))) / N
+    cf v[P];
+#pragma unroll
+    for (int n0 = 0; n0 < P; ++n0) {
+        const int n = t + T * n0;
+        cf X = cf{0.f, 0.f};
+        int i;
+        if (active) {
+            if (is_sync) {
+                // x_in = zchu[0:Ks] on used_bins_synch; synch_state never advances (:143-147)
+                if (bin_neg(n, tx.Ks, N, i)) X = tx.zc[i];
+                if (bin_pos(n, tx.Ks, i)) X = tx.zc[i];               // a bin listed twice keeps the later entry
+            } else if (fbits) {
+                bool has = bin_neg(n, tx.Kd, N, i);
+                int ip;
+                if (bin_pos(n, tx.Kd, ip)) {
+                    has = true;
+                    i = ip;
+                }
+                if (has) X = map_symbol(read_bits(fbits, a.bits_mode, (ds * tx.Kd + i) * tx.bps, tx.bps), tx.bps);
+            }
+        }
+        v[n0] = cconj(X);
+    }
+    wg_fft<N>(v, lds, tw, w1tab, t);                                         // :199
+    wg_barrier();
+    // natural-order time samples + energy / mean over the CP-extended symbol (:200-202,213)
+    float e = 0.f, sx = 0.f, sy = 0.f;
+    const float invn = 1.f / float(N);
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+        for (int kl = 0; kl < PL::RL; ++kl) {
+            const int m = (t + T * j) + PL::NC * kl;
+            const cf x = cscale(cconj(v[out_slot<N>(j, kl)]), invn);
+            lds[m] = x;
+            const float w = (m >= N - tx.cp) ? 2.f : 1.f;            // CP samples appear twice
+            e += w * cnorm2(x);
+            sx += w * x.x;
+            sy += w * x.y;
+        }
+    }
+    e = symbol_sum<T>(e, red, t);
+    if constexpr (T > 64) wg_barrier();
+    sx = symbol_sum<T>(sx, red, t);
+    if constexpr (T > 64) wg_barrier();
+    sy = symbol_sum<T>(sy, red, t);
+    wg_barrier();
+    const float Lf = float(tx.L);
+    const float a1 = (e > 1e-30f) ? sqrtf(Lf / e) : 1.f;              // :204-205
+    const float mx = a1 * sx / Lf, my = a1 * sy / Lf;
+    const float var = a1 * a1 * e / Lf - (mx * mx + my * my);         // np.var(data_time) :213
+    const float scale = a1 / sqrtf(var);                              // :218
+    if (active) {
+        cf* o = a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L;
+        for (int j = t; j < tx.L; j += T) {
+            int m = j - tx.cp;
+            if (m < 0) m += N;
+            o[j] = cscale(lds[m], scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ channel
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0;
+        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = uint32_t(p1);
+        const uint32_t n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = uint32_t(p0);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__global__ void __launch_bounds__(256) channel_kernel(ChanArgs a) {
+    const int frame = blockIdx.y;
+    const cf* in = a.in + int64_t(frame) * a.in_stride;
+    const cf* taps = a.taps + (a.per_frame_taps ? int64_t(frame) * a.n_taps : 0);
+    cf* out = a.out + int64_t(frame) * a.out_stride;
+    for (int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; n < a.out_len;
+         n += int64_t(gridDim.x) * blockDim.x) {
+        cf acc = cf{0.f, 0.f};
+        for (int l = 0; l < a.n_taps; ++l) {                          // np.convolve(tx_sig, chan) :227
+            const int64_t j = n - l;
+            if (j >= 0 && j < a.in_len) acc = acc + cmul(taps[l], in[j]);
+        }
+        if (a.noise_std > 0.f) {                                      // :258
+            uint32_t rnd[4];
+            philox4x32_10(uint32_t(n), uint32_t(uint64_t(n) >> 32), uint32_t(frame), 0u, uint32_t(a.seed),
+                          uint32_t(a.seed >> 32), rnd);
+            const float u1 = (float(rnd[0]) + 0.5f) * 2.3283064365386963e-10f;
+            const float u2 = (float(rnd[1]) + 0.5f) * 2.3283064365386963e-10f;
+            const float rr = sqrtf(-2.f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            acc.x += a.noise_std * rr * cs;
+            acc.y += a.noise_std * rr * sn;
+        }
+        out[n] = acc;
+    }
+}
+
+template <int N>
+static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s) {
+    const int64_t units = int64_t(a.n_frames) * a.n_sym;
+    const unsigned grid = unsigned((units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(tx_modulate_kernel<N>, dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, tx, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s) {
+    switch (tx.nfft) {
+        case 64: return launch_mod_n<64>(tx, a, s);
+        case 128: return launch_mod_n<128>(tx, a, s);
+        case 256: return launch_mod_n<256>(tx, a, s);
+        case 512: return launch_mod_n<512>(tx, a, s);
+        case 1024: return launch_mod_n<1024>(tx, a, s);
+        case 2048: return launch_mod_n<2048>(tx, a, s);
+        case 4096: return launch_mod_n<4096>(tx, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_channel(const ChanArgs& a, hipStream_t s) {
+    if (a.n_frames <= 0 || a.out_len <= 0) return hipSuccess;
+    const unsigned gx = unsigned(std::min<int64_t>((a.out_len + 255) / 256, 4096));
+    hipLaunchKernelGGL(channel_kernel, dim3(gx, unsigned(a.n_frames)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ofdm

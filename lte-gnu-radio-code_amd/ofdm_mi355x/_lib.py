@@ -1,0 +1,136 @@
+"""ctypes binding of libofdm_mi355x.so (C ABI: include/ofdm_mi355x.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded, importing
+any compute entry point raises ``OfdmLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("OFDM_MI355X_LIB", os.path.join(_HERE, "libofdm_mi355x.so"))
+
+OFDM_OK = 0
+OFDM_ERR_INVALID = -1
+OFDM_ERR_HIP = -2
+OFDM_ERR_INDEX = -3
+OFDM_ERR_SHAPE = -4
+OFDM_ERR_NOMEM = -5
+
+COMPAT_UTSA = 0
+COMPAT_RXOFDM = 1
+BITS_NONE, BITS_PACKED, BITS_UNPACKED = 0, 1, 2
+MODULATION_BITS = {"BPSK": 1, "QPSK": 2, "16QAM": 4, "64QAM": 6}
+
+
+class OfdmLibraryError(RuntimeError):
+    pass
+
+
+class OfdmError(RuntimeError):
+    pass
+
+
+class RxCfg(C.Structure):
+    _fields_ = [("num_ofdm_symb", C.c_int32), ("nfft", C.c_int32), ("cp_len", C.c_int32),
+                ("num_synch_bins", C.c_int32), ("synch_S", C.c_int32), ("synch_D", C.c_int32),
+                ("num_data_bins", C.c_int32), ("snr", C.c_double), ("scale_factor_gate", C.c_double),
+                ("compat", C.c_int32), ("modulation", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RxReport(C.Structure):
+    _fields_ = [("time_synch_ref", C.c_double * 3), ("detected", C.c_int32), ("trials_run", C.c_int32),
+                ("count", C.c_int32), ("corr_obs", C.c_int32), ("n_data_items", C.c_int64)]
+
+
+class TxCfg(C.Structure):
+    _fields_ = [("nfft", C.c_int32), ("cp_len", C.c_int32), ("num_synch_bins", C.c_int32),
+                ("num_data_bins", C.c_int32), ("synch_S", C.c_int32), ("synch_D", C.c_int32),
+                ("modulation", C.c_int32), ("zc_root", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes): exactly the prototypes of include/ofdm_mi355x.h
+PROTOTYPES = {
+    "ofdm_abi_version": (C.c_int, []),
+    "ofdm_last_error": (C.c_char_p, []),
+    "ofdm_device_malloc": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int64]),
+    "ofdm_device_free": (C.c_int, [C.c_int32, C.c_void_p]),
+    "ofdm_memcpy_h2d": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ofdm_memcpy_d2h": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ofdm_device_synchronize": (C.c_int, [C.c_int32]),
+    "ofdm_rx_create": (C.c_int, [C.POINTER(RxCfg), C.POINTER(C.c_void_p)]),
+    "ofdm_rx_destroy": (C.c_int, [C.c_void_p]),
+    "ofdm_rx_work": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(RxReport)]),
+    "ofdm_rx_get_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofdm_rx_demod_frames": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ofdm_rx_get_frame_state": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofdm_rx_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ofdm_demap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofdm_tx_create": (C.c_int, [C.POINTER(TxCfg), C.POINTER(C.c_void_p)]),
+    "ofdm_tx_destroy": (C.c_int, [C.c_void_p]),
+    "ofdm_tx_modulate_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                                          C.c_int64, C.c_void_p]),
+    "ofdm_channel_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises OfdmLibraryError when it is absent: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OfdmLibraryError(
+            "HIP library %s not found: build it with `make -C lte-gnu-radio-code_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)          # CDLL calls release the GIL (GNU Radio: one thread per block)
+    except OSError as e:
+        raise OfdmLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OfdmLibraryError("%s does not export %s" % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ofdm_abi_version() != 1:
+        raise OfdmLibraryError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ofdm_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    """Map a negative ofdm_status to the exception the reference's NumPy code would raise."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == OFDM_ERR_INDEX:
+        raise IndexError(msg)
+    if rc == OFDM_ERR_SHAPE or rc == OFDM_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == OFDM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise OfdmError(msg)
+
+
+def ptr(x):
+    """Device/host address of a torch tensor, numpy array, DeviceBuffer, int or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ctypes"):
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError("cannot take the address of %r" % type(x))

@@ -1,0 +1,212 @@
+"""Drop-in GNU Radio blocks: same class names, constructor orders and work() contract as the reference.
+
+  utsa_ofdm.SynchAndChanEst      gr-utsa_ofdm/python/SynchAndChanEst.py:16-262
+  utsa_ofdm.TxSignalTransmitter  gr-utsa_ofdm/python/TxSignalTransmitter.py:15-29
+  RXOFDM.synch_and_chan_est      gr-RXOFDM/python/synch_and_chan_est.py:16-266  (ctor/constants only, see below)
+  TXOFDM.tx_signal_transmitter   gr-TXOFDM/python/tx_signal_transmitter.py:13-27
+  OFDMReceiver.BitRecovery       LEGACY/gr-ofdm-rx/python/BitRecovery.py:32-189
+
+All signal processing happens in libofdm_mi355x.so (HIP kernels); these classes only marshal NumPy views.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+
+from . import _lib
+from .engine import DeviceBuffer, RxEngine, bins_p, zadoff_chu
+from .gr_compat import sync_block
+from .safe_pickle import load_ndarray
+
+
+def _device() -> int:
+    return int(os.environ.get("OFDM_MI355X_DEVICE", "0"))
+
+
+class SynchAndChanEst(sync_block):
+    """utsa_ofdm.SynchAndChanEst -- ZC timing sync + LS channel estimate + FFT/equalise (stream block)."""
+
+    _COMPAT = _lib.COMPAT_UTSA
+    _NAME = "SynchAndChanEst"
+
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
+                 scale_factor_gate, directory_name, file_name_cest, diagnostics, genie, channel="Fading"):
+        # GRC's make template passes 12 arguments (grc/utsa_ofdm_SynchAndChanEst.block.yml:7): `channel` defaults.
+        sync_block.__init__(self, name=self._NAME, in_sig=[np.complex64], out_sig=[np.complex64])
+        self.num_ofdm_symb = num_ofdm_symb
+        self.nfft = nfft
+        self.channel = channel
+        self.cp_len = cp_len
+        self.genie = genie
+        self.scale_factor_gate = scale_factor_gate
+        self.num_synch_bins = num_synch_bins
+        self.synch_dat = synch_dat
+        self.num_data_bins = num_data_bins
+        self.num_data_symbs_blk = synch_dat[1]
+        self.synch_bins_used_P = list(bins_p(num_synch_bins, nfft))            # :38-41
+        self.bins_used_P = list(bins_p(num_data_bins, nfft))                    # :66-70
+        self.L_synch = len(self.synch_bins_used_P)
+        self.M = [synch_dat[0], num_synch_bins]                                 # :48
+        self.MM = int(np.prod(self.M))
+        self.SNR = snr
+        if self._COMPAT == _lib.COMPAT_UTSA:
+            self.p = 23                                                         # :52
+            self.stride_val = 1                                                 # :77
+            self.SNR_lin = 10 ** (snr / 20)                                     # :99
+            self.zadoff_chu = zadoff_chu(self.MM, self.p)
+        else:
+            self.p = 37                                                         # gr-RXOFDM :54
+            self.stride_val = cp_len - 1                                        # :81
+            self.SNR_lin = snr
+            self.zadoff_chu = zadoff_chu(self.MM, self.p, parity_of=num_synch_bins)
+        self.start_samp = cp_len                                                # :78
+        self.rx_b_len = nfft + cp_len                                           # :79
+        self.diagnostic = diagnostics
+        self.directory_name = directory_name
+        self.file_name_cest = file_name_cest
+        self.num_ant_txrx = 1
+        self._engine = RxEngine(num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
+                                scale_factor_gate, compat=self._COMPAT, device=_device())
+        self.time_synch_ref = np.zeros(3)                                       # :83
+        self.count = 0                                                          # :100
+        self.corr_obs = -1                                                      # :72
+
+    # -- attributes the reference keeps as NumPy arrays; here they live in HBM and are fetched on access
+    def _rows(self, key, width):
+        out = np.zeros((self.num_ofdm_symb, width), dtype=complex)
+        for row in range(min(2, self.num_ofdm_symb)):
+            out[row] = self._engine.state(row)[key]
+        return out
+
+    @property
+    def est_chan_freq_P(self):
+        return self._rows("chan_freq", self.nfft)
+
+    @property
+    def est_chan_time(self):
+        return self._rows("chan_time", self.nfft)
+
+    @property
+    def est_synch_freq(self):
+        return self._rows("synch_freq", self.MM)
+
+    @property
+    def est_data_freq(self):
+        return self._engine.state(0)["data_freq"].astype(complex)
+
+    @property
+    def eq_gain(self):
+        return self._engine.state(0)["eq_gain"].astype(complex)
+
+    def work(self, input_items, output_items):
+        in0 = input_items[0]
+        out = output_items[0]
+        n = self._engine.work(in0, out)
+        rep = self._engine.report
+        self.time_synch_ref = np.array(rep.time_synch_ref[:], dtype=float)
+        self.count = rep.count
+        self.corr_obs = rep.corr_obs
+        if self.diagnostic == 1 and rep.detected:                               # :204-210 channel-estimate dump
+            row = 0 if self.count == 1 else min(1, self.num_ofdm_symb - 1)
+            chan_est_tim = self._engine.state(row)["chan_time"].astype(complex)[np.newaxis, :]
+            with open(str(self.directory_name) + "_" + str(self.file_name_cest), "wb") as f:
+                pickle.dump(chan_est_tim, f, protocol=2)
+        return n
+
+
+class synch_and_chan_est(SynchAndChanEst):  # noqa: N801  (reference class name)
+    """RXOFDM.synch_and_chan_est -- the class `ofdm_chain.py:83` instantiates.
+
+    The reference implementation of this generation raises AttributeError/TypeError on its first
+    detection under Python 3 (gr-RXOFDM/python/synch_and_chan_est.py:194,253); what is kept is its
+    constructor signature and constants (ZC root 37, search stride cp-1, gate 0.4, linear snr) on the
+    gr-utsa_ofdm control flow.
+    """
+
+    _COMPAT = _lib.COMPAT_RXOFDM
+
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
+                 directory_name, file_name_cest, diagnostics, genie):
+        SynchAndChanEst.__init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
+                                 0.4, directory_name, file_name_cest, diagnostics, genie)
+        self.diagnostics = diagnostics
+
+
+def _load_iq_file(path: str) -> np.ndarray:
+    """The reference unpickles the file (TxSignalTransmitter.py:22-24); here ndarray pickles are parsed
+    without executing them, and .npy files are accepted too."""
+    if path.endswith(".npy"):
+        arr = np.load(path, allow_pickle=False)
+    else:
+        arr = load_ndarray(path)
+    arr = np.asarray(arr)
+    if arr.ndim == 1:
+        arr = arr[np.newaxis, :]
+    return arr
+
+
+class TxSignalTransmitter(sync_block):
+    """utsa_ofdm.TxSignalTransmitter -- replays a stored IQ buffer into the output stream."""
+
+    def __init__(self, pickle_directory, pickle_file):
+        sync_block.__init__(self, name="SimpleTx", in_sig=None, out_sig=[np.complex64])
+        self.tx_data = _load_iq_file(str(pickle_directory) + str(pickle_file))
+
+    def work(self, input_items, output_items):
+        out = output_items[0]
+        out[0:self.tx_data.shape[1]] = self.tx_data[0, :]                       # :28 (complex128 -> complex64)
+        return len(output_items[0])                                             # :29
+
+
+class tx_signal_transmitter(TxSignalTransmitter):  # noqa: N801
+    """TXOFDM.tx_signal_transmitter(case, pickle_directory, pickle_file); `case` is ignored as in the reference."""
+
+    def __init__(self, case, pickle_directory, pickle_file):
+        TxSignalTransmitter.__init__(self, pickle_directory, pickle_file)
+        self.case = case
+
+
+class BitRecovery(sync_block):
+    """OFDMReceiver.BitRecovery -- QPSK hard decisions + max-log soft metrics (sink block)."""
+
+    def __init__(self, modulation, directory_name, diagnostics):
+        sync_block.__init__(self, name="BitRecovery", in_sig=[np.complex64], out_sig=None)
+        self.modulation = modulation
+        self.directory_name = directory_name
+        self.diagnostics = diagnostics
+        self.K = 1.414213562373095
+        self.count = 0
+        self._engine = RxEngine(1, 64, 16, 62, (1, 3), 60, 100, device=_device())
+        self.hardbit = None
+        self.softbit0 = None
+        self.softbit1 = None
+
+    def work(self, input_items, output_items):
+        in0 = np.ascontiguousarray(input_items[0], dtype=np.complex64)
+        n = in0.size
+        bps = _lib.MODULATION_BITS.get(str(self.modulation).upper().replace("-", ""), 2)
+        dev = self._engine.cfg.device
+        d_sym = DeviceBuffer(max(8, in0.nbytes), dev).upload(in0)
+        d_hard = DeviceBuffer(max(8, n * bps), dev)
+        soft = bps == 2
+        d_s0 = DeviceBuffer(max(8, n * bps * 4), dev) if soft else None
+        d_s1 = DeviceBuffer(max(8, n * bps * 4), dev) if soft else None
+        self._engine.demap(d_sym, n, bps, d_hard, d_s0, d_s1)
+        _lib.check(self._engine.lib.ofdm_device_synchronize(dev))
+        self.hardbit = d_hard.download(np.uint8, n * bps).astype(int)[:, np.newaxis]     # :155-157
+        if soft:
+            self.softbit0 = d_s0.download(np.float32, n * bps).astype(float)             # :147
+            self.softbit1 = d_s1.download(np.float32, n * bps).astype(float)             # :148
+        if self.diagnostics == 1 and soft:                                               # :167-184
+            import csv
+            import datetime
+            date_time = datetime.datetime.now().strftime("%Y_%m_%d_%Hh_%Mm")
+            for tag, arr in (("softbit0_", self.softbit0), ("softbit1_", self.softbit1)):
+                with open(self.directory_name + tag + date_time + ".pckl", "wb") as f:
+                    pickle.dump(arr, f, protocol=2)
+            with open(self.directory_name + "rx_data.csv", "a") as f:
+                csv.writer(f).writerows(self.hardbit)
+        self.count += 1                                                                  # :188
+        return len(input_items[0])                                                       # :189

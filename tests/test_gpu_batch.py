@@ -1,0 +1,215 @@
+"""GPU parity of the frame-batched device path, TX chain, channel and de-mapper (run with -m gpu)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import ofdm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def om():
+    import ofdm_mi355x
+    ofdm_mi355x.load()
+    return ofdm_mi355x
+
+
+def _frames(N, cp, Kd, n_sym, n_frames, mod, seed, tail):
+    """oracle TX + reference 5-tap channel per frame -> (bits[n_frames, nb], iq complex64 [n_frames, frame_len])"""
+    rng = np.random.default_rng(seed)
+    bps = orc.BITS_PER_SYMBOL[mod]
+    nb = (n_sym // 4) * 3 * Kd * bps
+    L = N + cp
+    bits = rng.integers(0, 2, (n_frames, nb)).astype(np.uint8)
+    iq = np.zeros((n_frames, n_sym * L + tail), np.complex64)
+    for f in range(n_frames):
+        tx = orc.tx_modulate(bits[f], N, cp, N - 2, Kd, n_sym, modulation=mod)
+        iq[f] = orc.channel_apply(tx, orc.REF_TAPS, N)[:n_sym * L + tail]
+    return bits, iq
+
+
+@pytest.mark.parametrize("N,cp,Kd,mod,n_frames,n_sym", [
+    (64, 16, 60, "QPSK", 19, 12),          # odd frame count: partially filled workgroups (8 symbols per wave)
+    (256, 18, 152, "16QAM", 5, 8),
+    (1024, 72, 600, "64QAM", 3, 8),
+    (2048, 144, 1200, "QPSK", 3, 8),
+    (2048, 144, 1200, "16QAM", 2, 12),
+    (2048, 144, 1200, "64QAM", 2, 8),
+    (4096, 288, 2400, "QPSK", 2, 4),
+])
+def test_batch_demod_vs_oracle(om, N, cp, Kd, mod, n_frames, n_sym):
+    L = N + cp
+    tail = cp + 5                                           # ragged: frame_len is not a multiple of L
+    bits, iq = _frames(N, cp, Kd, n_sym, n_frames, mod, seed=N + n_sym, tail=tail)
+    frame_len = iq.shape[1]
+    bps = orc.BITS_PER_SYMBOL[mod]
+    rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7, modulation=mod)
+    nds = rx.data_symbols_per_frame(frame_len)
+    assert nds == (n_sym // 4) * 3
+    d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+    d_eq = om.DeviceBuffer(n_frames * nds * Kd * 8)
+    d_bp = om.DeviceBuffer(n_frames * nds * Kd * bps // 8)
+    d_bu = om.DeviceBuffer(n_frames * nds * Kd * bps)
+    d_tsr = om.DeviceBuffer(n_frames * 16)
+    assert rx.demod_frames(d_iq, n_frames, frame_len, frame_len, d_eq, d_bp, om.BITS_PACKED, d_tsr) == nds
+    rx.demod_frames(d_iq, n_frames, frame_len, frame_len, None, d_bu, om.BITS_UNPACKED, None)
+    eq = d_eq.download(np.complex64, n_frames * nds * Kd).reshape(n_frames, nds, Kd)
+    bp = d_bp.download(np.uint8, n_frames * nds * Kd * bps // 8).reshape(n_frames, -1)
+    bu = d_bu.download(np.uint8, n_frames * nds * Kd * bps).reshape(n_frames, -1)
+    tsr = d_tsr.download(np.int32, n_frames * 4).reshape(n_frames, 4)
+    rows = [r for r in range(n_sym) if r % 4 != 3]
+    for f in range(n_frames):
+        o = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 100, 0.7, force_fp64=True)
+        o.work(iq[f], np.zeros(frame_len, np.complex64))
+        assert tsr[f, 0] == o.time_synch_ref[0] and tsr[f, 1] == o.time_synch_ref[1] and tsr[f, 3] == 1
+        assert abs(tsr[f, 2] - o.time_synch_ref[2]) <= 1
+        assert relerr(eq[f], o.est_data_freq[rows]) < TOL
+        st = rx.frame_state(f)
+        assert relerr(st["chan_freq"], o.est_chan_freq_P[0]) < TOL
+        assert relerr(st["chan_time"], o.est_chan_time[0]) < TOL
+        # bits: exact vs the transmitted bits and vs the oracle's de-map of the GPU's own equalised symbols
+        assert np.array_equal(bu[f], orc.demap_hard(eq[f].ravel(), mod))
+        assert np.array_equal(np.unpackbits(bp[f]), bu[f])
+        if mod == "QPSK":
+            assert np.array_equal(bu[f], bits[f])
+
+
+def test_batch_frames_without_sync_and_short_frames(om):
+    """Frame 1 is pure noise (no detection -> zeros, detected flag 0); frames shorter than a pattern give 0 symbols."""
+    N, cp, Kd, n_sym = 64, 16, 60, 8
+    bits, iq = _frames(N, cp, Kd, n_sym, 3, "QPSK", seed=1, tail=0)
+    rng = np.random.default_rng(0)
+    iq[1] = (0.01 * (rng.standard_normal(iq.shape[1]) + 1j * rng.standard_normal(iq.shape[1]))).astype(np.complex64)
+    rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+    fl = iq.shape[1]
+    nds = rx.data_symbols_per_frame(fl)
+    d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+    d_eq = om.DeviceBuffer(3 * nds * Kd * 8)
+    d_tsr = om.DeviceBuffer(3 * 16)
+    rx.demod_frames(d_iq, 3, fl, fl, d_eq, None, om.BITS_NONE, d_tsr)
+    eq = d_eq.download(np.complex64, 3 * nds * Kd).reshape(3, nds, Kd)
+    tsr = d_tsr.download(np.int32, 12).reshape(3, 4)
+    assert list(tsr[:, 3]) == [1, 0, 1] and not tsr[1].any()
+    assert not eq[1].any() and eq[0].any() and eq[2].any()
+    assert rx.demod_frames(d_iq, 3, fl, 3 * 80, d_eq, None, om.BITS_NONE, None) == 0      # < one [1,3] pattern
+    assert rx.demod_frames(d_iq, 0, fl, fl, d_eq, None, om.BITS_NONE, None) == nds        # empty batch is a no-op
+    with pytest.raises(ValueError):
+        rx.demod_frames(d_iq, 3, fl - 1, fl, d_eq, None, om.BITS_NONE, None)              # stride < length
+
+
+@pytest.mark.parametrize("N,cp,Kd,mod", [(64, 16, 60, "QPSK"), (64, 16, 60, "BPSK"), (256, 18, 152, "16QAM"),
+                                         (1024, 72, 600, "64QAM"), (2048, 144, 1200, "QPSK"), (4096, 288, 2400, "16QAM")])
+def test_tx_chain_vs_oracle(om, N, cp, Kd, mod):
+    rng = np.random.default_rng(N + len(mod))
+    n_sym, n_frames = 8, 3
+    bps = orc.BITS_PER_SYMBOL[mod]
+    tx = om.TxEngine(N, cp, N - 2, Kd, (1, 3), mod)
+    nb = tx.bits_per_frame(n_sym)
+    assert nb == 6 * Kd * bps
+    bits = rng.integers(0, 2, (n_frames, nb)).astype(np.uint8)
+    L = N + cp
+    d_bits = om.DeviceBuffer(bits.nbytes).upload(bits)
+    d_iq = om.DeviceBuffer(n_frames * n_sym * L * 8)
+    tx.modulate_frames(d_bits, n_frames, n_sym, d_iq, bits_mode=om.BITS_UNPACKED)
+    iq = d_iq.download(np.complex64, n_frames * n_sym * L).reshape(n_frames, -1)
+    for f in range(n_frames):
+        assert relerr(iq[f], orc.tx_modulate(bits[f], N, cp, N - 2, Kd, n_sym, modulation=mod)) < TOL
+    if nb % 8 == 0:
+        pk = np.packbits(bits, axis=1)
+        d_pk = om.DeviceBuffer(pk.nbytes).upload(pk)
+        d_iq2 = om.DeviceBuffer(n_frames * n_sym * L * 8)
+        tx.modulate_frames(d_pk, n_frames, n_sym, d_iq2, bits_mode=om.BITS_PACKED)
+        assert np.array_equal(d_iq2.download(np.complex64, n_frames * n_sym * L), iq.ravel())
+
+
+def test_tx_chain_reproduces_reference_fixture(om, golden):
+    """bits fixture -> HIP TX == reference tx_data_online fixture (the file the reference TX block replays)."""
+    fx = golden("ref_fixtures.npz")
+    tx = om.TxEngine(64, 16, 62, 60, (1, 3), "QPSK")
+    bits = fx["tx_bits"][0].astype(np.uint8)
+    d_bits = om.DeviceBuffer(bits.nbytes).upload(bits)
+    d_iq = om.DeviceBuffer(19200 * 8)
+    tx.modulate_frames(d_bits, 1, 240, d_iq)
+    assert relerr(d_iq.download(np.complex64, 19200), fx["tx_online"][0]) < TOL
+
+
+def test_channel_vs_oracle_and_noise_statistics(om, golden):
+    fx = golden("ref_fixtures.npz")
+    x = fx["tx_online"][0].astype(np.complex64)
+    taps = (orc.REF_TAPS / np.linalg.norm(orc.REF_TAPS)).astype(np.complex64)
+    tx = om.TxEngine(64, 16, 62, 60)
+    d_x = om.DeviceBuffer(x.nbytes).upload(x)
+    d_t = om.DeviceBuffer(taps.nbytes).upload(taps)
+    n_out = len(x) + len(taps) - 1
+    d_y = om.DeviceBuffer(n_out * 8)
+    tx.channel(d_x, 1, len(x), len(x), d_t, len(taps), d_y, n_out, n_out)
+    y = d_y.download(np.complex64, n_out)
+    ref = orc.channel_apply(x, orc.REF_TAPS, 64)[:n_out]
+    assert relerr(y, ref) < TOL
+    assert np.max(np.abs(y - fx["tx_offline"][0][:n_out])) < 2e-4          # reference fixture carries 100 dB AWGN
+    # AWGN: variance, zero mean, I/Q balance, reproducible from the seed, different per seed
+    nv = 0.25
+    tx.channel(d_x, 1, len(x), len(x), d_t, len(taps), d_y, n_out, n_out, noise_var=nv, seed=1234)
+    n1 = d_y.download(np.complex64, n_out) - y
+    tx.channel(d_x, 1, len(x), len(x), d_t, len(taps), d_y, n_out, n_out, noise_var=nv, seed=1234)
+    assert np.array_equal(d_y.download(np.complex64, n_out) - y, n1)
+    tx.channel(d_x, 1, len(x), len(x), d_t, len(taps), d_y, n_out, n_out, noise_var=nv, seed=99)
+    assert not np.array_equal(d_y.download(np.complex64, n_out) - y, n1)
+    assert abs(np.var(n1) / nv - 1) < 0.05 and abs(np.mean(n1)) < 0.02
+    assert abs(np.var(n1.real) / np.var(n1.imag) - 1) < 0.1
+
+
+def test_demap_vs_reference_bitrecovery(om, golden):
+    import OFDMReceiver
+    g = golden("ref_bitrecovery.npz")
+    blk = OFDMReceiver.BitRecovery("QPSK", "/tmp/", 0)
+    assert blk.work([g["z"]], [None]) == len(g["z"])
+    nz = np.repeat((g["z"].real != 0) & (g["z"].imag != 0), 2)
+    assert np.array_equal(blk.hardbit.ravel()[nz], g["hardbit"][nz])
+    assert relerr(blk.softbit0[nz], g["softbit0"][nz]) < TOL
+    assert relerr(blk.softbit1[nz], g["softbit1"][nz]) < TOL
+    # outlier flip + all modulations, hard decisions vs the oracle
+    rng = np.random.default_rng(2)
+    z = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+    rx = om.RxEngine(1, 64, 16, 62, (1, 3), 60, 100)
+    d_z = om.DeviceBuffer(z.nbytes).upload(z)
+    for mod in ("BPSK", "QPSK", "16QAM", "64QAM"):
+        bps = orc.BITS_PER_SYMBOL[mod]
+        d_h = om.DeviceBuffer(len(z) * bps)
+        rx.demap(d_z, len(z), mod, d_h)
+        om.load().ofdm_device_synchronize(0)
+        assert np.array_equal(d_h.download(np.uint8, len(z) * bps), orc.demap_hard(z, mod))
+
+
+def test_loopback_property_full_size_numerology(om):
+    """2048/144/1200 at a size the oracle would need minutes for: bits -> HIP TX -> HIP channel(+AWGN 30 dB)
+    -> HIP RX -> bits is the identity; and the equaliser output is invariant to a common input gain."""
+    N, cp, Kd, n_sym, n_frames = 2048, 144, 1200, 240, 12
+    L = N + cp
+    rng = np.random.default_rng(0)
+    txe = om.TxEngine(N, cp, N - 2, Kd, (1, 3), "QPSK")
+    rxe = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 30, 0.7)
+    nb = txe.bits_per_frame(n_sym)
+    bits = rng.integers(0, 2, (n_frames, nb)).astype(np.uint8)
+    d_bits = om.DeviceBuffer(bits.nbytes).upload(bits)
+    fl = n_sym * L
+    d_tx = om.DeviceBuffer(n_frames * fl * 8)
+    d_rx = om.DeviceBuffer(n_frames * fl * 8)
+    taps = (orc.REF_TAPS / np.linalg.norm(orc.REF_TAPS)).astype(np.complex64)
+    d_t = om.DeviceBuffer(taps.nbytes).upload(taps)
+    txe.modulate_frames(d_bits, n_frames, n_sym, d_tx)
+    txe.channel(d_tx, n_frames, fl, fl, d_t, len(taps), d_rx, fl, fl, noise_var=1e-3, seed=7)
+    nds = rxe.data_symbols_per_frame(fl)
+    d_out = om.DeviceBuffer(n_frames * nds * Kd * 2)
+    d_eq = om.DeviceBuffer(n_frames * nds * Kd * 8)
+    assert rxe.demod_frames(d_rx, n_frames, fl, fl, d_eq, d_out, om.BITS_UNPACKED, None) == 180
+    got = d_out.download(np.uint8, n_frames * nds * Kd * 2).reshape(n_frames, -1)
+    assert np.array_equal(got, bits)
+    eq1 = d_eq.download(np.complex64, n_frames * nds * Kd)
+    # scale invariance (per-symbol power normalisation on both sync and data paths)
+    x = d_rx.download(np.complex64, n_frames * fl)
+    d_rx.upload((x * np.complex64(3.0)).astype(np.complex64))
+    rxe.demod_frames(d_rx, n_frames, fl, fl, d_eq, None, om.BITS_NONE, None)
+    assert relerr(d_eq.download(np.complex64, n_frames * nds * Kd), eq1) < TOL
