@@ -146,12 +146,12 @@ int ofdm_device_synchronize(int32_t device) {
 // ------------------------------------------------------------------------------------------ RX
 int ofdm_rx_destroy(ofdm_rx* h) {
     if (!h) return OFDM_OK;
-    hipSetDevice(h->cfg.device);
+    (void)hipSetDevice(h->cfg.device);
     void* ptrs[] = {h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
                     h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    if (h->stream) hipStreamDestroy(h->stream);
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return OFDM_OK;
 }
@@ -263,7 +263,7 @@ int ofdm_rx_reserve(ofdm_rx* h, int64_t n_frames) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipDeviceSynchronize());
     for (void* p : {(void*)h->f_tsr, (void*)h->f_H, (void*)h->f_gain, (void*)h->f_htime})
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     h->f_tsr = nullptr;
     h->f_H = h->f_gain = h->f_htime = nullptr;
     h->cap_frames = 0;
@@ -381,7 +381,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
 
     if (n_in > h->in_cap) {
         HIP_TRY(hipStreamSynchronize(s));
-        if (h->d_in) hipFree(h->d_in);
+        if (h->d_in) (void)hipFree(h->d_in);
         h->d_in = nullptr;
         h->in_cap = 0;
         const int64_t cap = n_in + n_in / 4 + 1024;
@@ -468,6 +468,19 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         }
     }
 
+    auto fill_report = [&]() {
+        if (!rep) return;
+        rep->time_synch_ref[0] = h->tsr[0];
+        rep->time_synch_ref[1] = h->tsr[1];
+        rep->time_synch_ref[2] = h->tsr[2];
+        rep->detected = detected;
+        rep->trials_run = trials_run;
+        rep->count = h->count;
+        rep->corr_obs = h->corr_obs;
+        rep->n_data_items = n_data_symb * Kd;
+    };
+    fill_report();   // valid even if the call fails below, like the attributes the reference has already updated
+
     // ---------------- Loop B: data demod (:221-248)
     const int64_t tsr0 = int64_t(h->tsr[0]);
     int64_t n_pat_loop = (n_unique + SD - 1) / SD;                           // range(n_unique)[::S+D]
@@ -531,16 +544,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
     }
     h->count += 1;                                                           // :260
     h->corr_obs = 0;                                                         // :261
-    if (rep) {
-        rep->time_synch_ref[0] = h->tsr[0];
-        rep->time_synch_ref[1] = h->tsr[1];
-        rep->time_synch_ref[2] = h->tsr[2];
-        rep->detected = detected;
-        rep->trials_run = trials_run;
-        rep->count = h->count;
-        rep->corr_obs = h->corr_obs;
-        rep->n_data_items = n_data_symb * Kd;
-    }
+    fill_report();
     return n_out;                                                            // :262
 }
 
@@ -567,10 +571,10 @@ int ofdm_demap(ofdm_rx* h, const float* d_sym, int64_t n, int32_t modulation, ui
 // ------------------------------------------------------------------------------------------ TX
 int ofdm_tx_destroy(ofdm_tx* h) {
     if (!h) return OFDM_OK;
-    hipSetDevice(h->cfg.device);
-    if (h->d_tw) hipFree(h->d_tw);
-    if (h->d_zc) hipFree(h->d_zc);
-    if (h->stream) hipStreamDestroy(h->stream);
+    (void)hipSetDevice(h->cfg.device);
+    if (h->d_tw) (void)hipFree(h->d_tw);
+    if (h->d_zc) (void)hipFree(h->d_zc);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return OFDM_OK;
 }

@@ -103,11 +103,13 @@ class SynchAndChanEst(sync_block):
     def work(self, input_items, output_items):
         in0 = input_items[0]
         out = output_items[0]
-        n = self._engine.work(in0, out)
+        rc = self._engine.work(in0, out)
         rep = self._engine.report
+        # the reference updates these before any later IndexError / ValueError of the same call
         self.time_synch_ref = np.array(rep.time_synch_ref[:], dtype=float)
         self.count = rep.count
         self.corr_obs = rep.corr_obs
+        n = _lib.check(rc)
         if self.diagnostic == 1 and rep.detected:                               # :204-210 channel-estimate dump
             row = 0 if self.count == 1 else min(1, self.num_ofdm_symb - 1)
             chan_est_tim = self._engine.state(row)["chan_time"].astype(complex)[np.newaxis, :]

@@ -54,8 +54,11 @@ class DeviceBuffer:
         return self
 
     def download(self, dtype, count: int) -> np.ndarray:
+        """Blocking device-to-host copy; waits for ALL streams of the device first (the batch entry points
+        are asynchronous on the handles' non-blocking streams)."""
         out = np.empty(count, dtype=dtype)
         assert out.nbytes <= self.nbytes
+        check(self.lib.ofdm_device_synchronize(self.device))
         check(self.lib.ofdm_memcpy_d2h(self.device, ptr(out), ptr(self), out.nbytes))
         return out
 
@@ -87,14 +90,16 @@ class RxEngine:
 
     # ---- stream block -----------------------------------------------------------------------
     def work(self, in0: np.ndarray, out: np.ndarray) -> int:
+        """Returns the raw status; the caller copies `self.report` (valid even when the reference would have
+        raised after its sync search) and then passes the status to `_lib.check`."""
         in0 = np.ascontiguousarray(in0, dtype=np.complex64)
         if out.dtype != np.complex64 or not out.flags.c_contiguous:
             tmp = np.ascontiguousarray(out, dtype=np.complex64)
-            rc = check(self.lib.ofdm_rx_work(self._h, ptr(in0), in0.size, ptr(tmp), tmp.size, C.byref(self.report)))
-            out[...] = tmp
+            rc = self.lib.ofdm_rx_work(self._h, ptr(in0), in0.size, ptr(tmp), tmp.size, C.byref(self.report))
+            if rc >= 0:
+                out[...] = tmp
             return int(rc)
-        return int(check(self.lib.ofdm_rx_work(self._h, ptr(in0), in0.size, ptr(out), out.size,
-                                               C.byref(self.report))))
+        return int(self.lib.ofdm_rx_work(self._h, ptr(in0), in0.size, ptr(out), out.size, C.byref(self.report)))
 
     def state(self, row: int = 0):
         c = self.cfg
