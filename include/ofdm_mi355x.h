@@ -111,6 +111,16 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
  * h_chan_freq[nfft], h_gain[Kd] (equaliser gain incl. lag de-rotation), h_chan_time[nfft]. NULL = skip. */
 int ofdm_rx_get_frame_state(ofdm_rx* h, int64_t frame, float* h_chan_freq, float* h_gain, float* h_chan_time);
 
+/* Optional HIP-event timing of the two kernels ofdm_rx_demod_frames launches (bench.py's roofline leg).
+ * enable != 0 records events around the sync kernel and the demod kernel on the launch stream;
+ * ofdm_rx_get_kernel_ms synchronises on the last recorded event and returns the durations of the LAST call. */
+int ofdm_rx_set_profiling(ofdm_rx* h, int32_t enable);
+int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms);
+
+/* Upper bound on sync trials per frame in the batch path (0 = none: scan the whole frame like the
+ * reference, :143).  A frame with no sync costs one FFT pair per sample, so hosts may cap it. */
+int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials);
+
 /* Bytes of device workspace the batch path needs for n_frames (allocated lazily, grown on demand
  * OUTSIDE the asynchronous section: call ofdm_rx_reserve before capturing into a hipGraph). */
 int ofdm_rx_reserve(ofdm_rx* h, int64_t n_frames);

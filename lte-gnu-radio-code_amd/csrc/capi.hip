@@ -100,6 +100,9 @@ struct ofdm_rx {
     cf* f_H = nullptr;
     cf* f_gain = nullptr;
     cf* f_htime = nullptr;
+    int max_trials = 0;
+    bool profiling = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
 struct ofdm_tx {
@@ -151,8 +154,34 @@ int ofdm_rx_destroy(ofdm_rx* h) {
                     h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return OFDM_OK;
+}
+
+int ofdm_rx_set_profiling(ofdm_rx* h, int32_t enable) {
+    if (!h) return fail(OFDM_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (enable && !h->ev[0])
+        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+    h->profiling = enable != 0;
+    return OFDM_OK;
+}
+
+int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms) {
+    if (!h || !h->ev[0]) return fail(OFDM_ERR_INVALID, "profiling was not enabled");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipEventSynchronize(h->ev[2]));
+    if (sync_ms) HIP_TRY(hipEventElapsedTime(sync_ms, h->ev[0], h->ev[1]));
+    if (demod_ms) HIP_TRY(hipEventElapsedTime(demod_ms, h->ev[1], h->ev[2]));
+    return OFDM_OK;
+}
+
+int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials) {
+    if (!h || max_trials < 0) return fail(OFDM_ERR_INVALID, "bad argument");
+    h->max_trials = max_trials;
     return OFDM_OK;
 }
 
@@ -308,14 +337,16 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
     sa.n_frames = int(n_frames);
     sa.mode = 0;
     sa.p_begin = 0;
-    sa.p_count = 0;
+    sa.p_count = h->max_trials;
     sa.force_accept = 0;
     sa.tsr = h->f_tsr;
     sa.H = h->f_H;
     sa.H_for_gain = nullptr;
     sa.gain = h->f_gain;
     sa.htime = h->f_htime;
+    if (h->profiling) HIP_TRY(hipEventRecord(h->ev[0], s));
     HIP_TRY(launch_rx_sync(d, sa, s));
+    if (h->profiling) HIP_TRY(hipEventRecord(h->ev[1], s));
 
     if (n_dsym > 0 && (d_eq || d_bits)) {
         DemodArgs da{};
@@ -341,6 +372,7 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
         da.zero_skipped = 1;
         HIP_TRY(launch_rx_demod(d, da, s));
     }
+    if (h->profiling) HIP_TRY(hipEventRecord(h->ev[2], s));
     if (d_tsr) HIP_TRY(hipMemcpyAsync(d_tsr, h->f_tsr, size_t(n_frames) * 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return n_dsym;
 }

@@ -126,6 +126,18 @@ class RxEngine:
                                                        int(frame_len), ptr(d_eq), ptr(d_bits), int(bits_mode),
                                                        ptr(d_tsr), ptr(stream))))
 
+    def set_profiling(self, enable: bool = True):
+        check(self.lib.ofdm_rx_set_profiling(self._h, int(bool(enable))))
+
+    def kernel_ms(self):
+        """(sync_ms, demod_ms) of the last demod_frames call (needs set_profiling(True))."""
+        a, b = C.c_float(), C.c_float()
+        check(self.lib.ofdm_rx_get_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def set_max_trials(self, n: int):
+        check(self.lib.ofdm_rx_set_max_trials(self._h, int(n)))
+
     def frame_state(self, frame: int):
         c = self.cfg
         H = np.zeros(c.nfft, np.complex64)

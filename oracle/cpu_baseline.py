@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""CPU baseline leg of bench.py (TEST/MEASUREMENT INFRASTRUCTURE, never on the product path).
+
+Runs in its own process (no GPU state) on a bounded sample of the bench workload saved as .npy:
+ (i)  `rx_work_faithful_ops`: the reference block's operation structure (dense diag matmuls, per-symbol np.fft.fft)
+ (ii) `rx_demod_frames_vectorised`: honest batched-FFT NumPy, one worker process per host core
+Prints one JSON object.
+"""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ofdm_oracle as orc  # noqa: E402
+
+
+def _vec_job(iq, frame_len, ocfg):
+    orc.rx_demod_frames_vectorised(iq, frame_len, ocfg)
+    return 0
+
+
+def main():
+    path, cfg = sys.argv[1], json.loads(sys.argv[2])
+    budget_s = float(sys.argv[3]) if len(sys.argv) > 3 else 12.0
+    iq = np.load(path)                      # (n_frames, frame_len) complex64
+    N, cp, Kd, snr = cfg["nfft"], cfg["cp"], cfg["Kd"], cfg["snr_db"]
+    L = N + cp
+    frame_len = iq.shape[1]
+    n_sym_i = 16 if N >= 1024 else min(240, frame_len // L)
+    sample = iq[0][: n_sym_i * L]
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        rx = orc.RxOracle(n_sym_i, N, cp, N - 2, [1, 3], Kd, snr, 0.7)
+        orc.rx_work_faithful_ops(rx, sample)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or reps >= 200:
+            break
+    faithful = reps * len(sample) / dt / 1e6
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16, len(iq))
+    ocfg = dict(nfft=N, cp_len=cp, synch_dat=(1, 3), num_synch_bins=N - 2, num_data_bins=Kd, snr=snr)
+    per = max(1, len(iq) // cores)
+    jobs = [(iq[i * per:(i + 1) * per].reshape(-1), frame_len, ocfg) for i in range(cores)]
+    os.environ["OMP_NUM_THREADS"] = "1"
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        pool.starmap(_vec_job, jobs)
+    dtv = time.perf_counter() - t0
+    vec = sum(len(j[0]) for j in jobs) / dtv / 1e6
+    print(json.dumps(dict(
+        value=round(faithful, 4), unit="Msamples/s", cores=int(blas_threads), kind="port",
+        sample="%d symbols (%d samples) of frame 0 through oracle.rx_work_faithful_ops (reference op structure: dense diag "
+               "matmuls, per-symbol np.fft.fft; BLAS threads = cores), %d repetitions in %.1f s" % (n_sym_i, len(sample), reps, dt),
+        vectorised=dict(value=round(vec, 3), unit="Msamples/s", cores=len(jobs),
+                        sample="%d frames x %d samples, batched-FFT NumPy (oracle.rx_demod_frames_vectorised), one process per core, %.1f s"
+                               % (per * len(jobs), frame_len, dtv)))))
+
+
+if __name__ == "__main__":
+    main()
