@@ -40,9 +40,12 @@ __device__ __forceinline__ unsigned hard_bits(cf z, int bps) {
 // list position i (0..Kd-1) of the reference's bins_used_P  ->  FFT bin k
 __device__ __forceinline__ int list_to_bin(int i, int K, int N) { return (i < (K >> 1)) ? N - (K >> 1) + i : i - (K >> 1) + 1; }
 
-// GREG: keep the lane's equaliser gains in VGPRs across the symbol loop (32 VGPRs) instead of
-// re-reading them (L2-resident, coalesced 16 B/lane) for every symbol.
-template <int N, bool GREG>
+// GMODE: where the frame's equaliser gains live while a chunk of its symbols is processed.
+//   0 = re-read from global memory for every symbol (r01 v1: the stream thrashes L2, so these 8 B/bin
+//       re-reads reach the fabric -- +35 % HBM traffic, profiles/r01_v1_pmc_traffic.json)
+//   1 = 32 VGPRs per lane (costs a wave of occupancy per SIMD)
+//   2 = a Kd-entry LDS copy per symbol slot, filled once per chunk (default)
+template <int N, int GMODE>
 __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P, Q = P / 4;
@@ -72,8 +75,16 @@ __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, Demo
 
     // equaliser gains of this lane's output positions (4 consecutive list entries per q), fixed for the chunk
     const cf* gain = a.gain + int64_t(frame) * Kd;
-    cf g[GREG ? Q : 1][4];
-    if constexpr (GREG) {
+    const int Kd_pad = (Kd + 1) & ~1;
+    cf* glds = smem + WgLds<N>::STRIDE * PL::SLOTS + WgLds<N>::W1_ELEMS + slot * Kd_pad;
+    if constexpr (GMODE == 2) {
+        for (int i = 2 * t; i < Kd; i += 2 * T) {      // Kd is even: whole 16 B pairs; published by the FFT's first barrier
+            const float4 gg = active ? *reinterpret_cast<const float4*>(gain + i) : float4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<float4*>(glds + i) = gg;
+        }
+    }
+    cf g[GMODE == 1 ? Q : 1][4];
+    if constexpr (GMODE == 1) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int idx = 4 * (t + T * q);
@@ -144,12 +155,13 @@ __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, Demo
                 if (idx < Kd_) {
                     const bool four = idx + 2 < Kd_;
                     cf z[4], gq[4];
-                    if constexpr (GREG) {
+                    if constexpr (GMODE == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) gq[e] = g[q][e];
                     } else {
-                        const float4 g01 = *reinterpret_cast<const float4*>(gain + idx);
-                        const float4 g23 = four ? *reinterpret_cast<const float4*>(gain + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
+                        const cf* gsrc = (GMODE == 2) ? glds : gain;
+                        const float4 g01 = *reinterpret_cast<const float4*>(gsrc + idx);
+                        const float4 g23 = four ? *reinterpret_cast<const float4*>(gsrc + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
                         gq[0] = cf{g01.x, g01.y};
                         gq[1] = cf{g01.z, g01.w};
                         gq[2] = cf{g23.x, g23.y};
@@ -512,7 +524,8 @@ static hipError_t launch_demod_n(const RxDev& rx, const DemodArgs& a, hipStream_
     const int64_t chunks = int64_t(a.n_frames) * a.chunks_per_frame;
     const unsigned grid = unsigned((chunks + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL((rx_demod_kernel<N, false>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
+    const size_t lds = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * ((rx.Kd + 1) & ~1) * sizeof(cf);
+    hipLaunchKernelGGL((rx_demod_kernel<N, 2>), dim3(grid), dim3(Plan<N>::WG), lds, s, rx, a);
     return hipGetLastError();
 }
 template <int N>
