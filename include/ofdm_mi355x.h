@@ -117,6 +117,10 @@ int ofdm_rx_get_frame_state(ofdm_rx* h, int64_t frame, float* h_chan_freq, float
 int ofdm_rx_set_profiling(ofdm_rx* h, int32_t enable);
 int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms);
 
+/* Kernel tuning variant of the demod kernel (0 = shipped default; other values select alternative
+ * register/LDS/prefetch trade-offs compiled into the library).  Results are identical. */
+int ofdm_rx_set_variant(ofdm_rx* h, int32_t variant);
+
 /* Upper bound on sync trials per frame in the batch path (0 = none: scan the whole frame like the
  * reference, :143).  A frame with no sync costs one FFT pair per sample, so hosts may cap it. */
 int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials);

@@ -101,6 +101,7 @@ struct ofdm_rx {
     cf* f_gain = nullptr;
     cf* f_htime = nullptr;
     int max_trials = 0;
+    int variant = 0;
     bool profiling = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -176,6 +177,12 @@ int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms) {
     HIP_TRY(hipEventSynchronize(h->ev[2]));
     if (sync_ms) HIP_TRY(hipEventElapsedTime(sync_ms, h->ev[0], h->ev[1]));
     if (demod_ms) HIP_TRY(hipEventElapsedTime(demod_ms, h->ev[1], h->ev[2]));
+    return OFDM_OK;
+}
+
+int ofdm_rx_set_variant(ofdm_rx* h, int32_t variant) {
+    if (!h || variant < 0) return fail(OFDM_ERR_INVALID, "bad argument");
+    h->variant = variant;
     return OFDM_OK;
 }
 
@@ -370,6 +377,7 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
         da.row_stride_pat = d.D;
         da.rows_per_frame = int(n_dsym);
         da.zero_skipped = 1;
+        da.variant = h->variant;
         HIP_TRY(launch_rx_demod(d, da, s));
     }
     if (h->profiling) HIP_TRY(hipEventRecord(h->ev[2], s));
@@ -546,6 +554,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         da.row_stride_pat = SD;
         da.rows_per_frame = h->cfg.num_ofdm_symb;
         da.zero_skipped = 0;
+        da.variant = h->variant;
         HIP_TRY(launch_rx_demod(d, da, s));
     }
 

@@ -42,8 +42,13 @@ __device__ __forceinline__ float lanes_sum(float v) {
     return v;
 }
 
-// workgroup barrier (also orders LDS accesses)
-__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+// Workgroup barrier that orders LDS traffic ONLY.  Every barrier in these kernels protects an LDS exchange
+// (no lane ever reads another lane's global-memory writes), so unlike __syncthreads() it does not drain
+// the vector-memory queue: `s_waitcnt vmcnt(0)` before each of the 6 barriers per symbol would expose
+// the latency of the symbol's own output stores (CDNA4 counts stores in vmcnt) and of any load in flight.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Sum over all T lanes of one symbol.  `red` = 8 floats of LDS scratch per symbol slot (only used when T > 64).
 // Contains one workgroup barrier when T > 64 (all lanes of the workgroup must call it).

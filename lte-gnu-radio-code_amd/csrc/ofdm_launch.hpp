@@ -24,6 +24,7 @@ struct DemodArgs {
     int row_stride_pat;      // output row = p*row_stride_pat + n   (S+D in stream mode, D in batch mode)
     int rows_per_frame;
     int zero_skipped;        // write zeros for patterns whose guard fails (batch mode)
+    int variant;             // kernel tuning variant (0 = default)
 };
 
 // ---- RX sync search + LS estimate (reference: SynchAndChanEst.py:143-219, "Loop A") -----------

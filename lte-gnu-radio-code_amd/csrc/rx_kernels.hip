@@ -45,8 +45,10 @@ __device__ __forceinline__ int list_to_bin(int i, int K, int N) { return (i < (K
 //       re-reads reach the fabric -- +35 % HBM traffic, profiles/r01_v1_pmc_traffic.json)
 //   1 = 32 VGPRs per lane (costs a wave of occupancy per SIMD)
 //   2 = a Kd-entry LDS copy per symbol slot, filled once per chunk (default)
-template <int N, int GMODE>
-__global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, DemodArgs a) {
+// PREFETCH: register double buffer -- issue the loads of symbol it+1 before the FFT of symbol it.
+// MINW: minimum waves per SIMD requested from the register allocator (__launch_bounds__ 2nd argument).
+template <int N, int GMODE, bool PREFETCH, int MINW>
+__global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P, Q = P / 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -93,45 +95,94 @@ __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, Demo
         }
     }
 
-    for (int it = 0; it < a.spc; ++it) {
+    // symbol `ds` of this chunk: where its N-sample window starts and whether it is computed at all
+    struct SymInfo {
+        bool valid, compute;
+        int row;
+        int64_t start;
+    };
+    auto sym_info = [&](int it) {
+        SymInfo si;
         const int ds = ds0 + it;
-        const bool sym_valid = active && ds < ds1;
+        si.valid = active && it < a.spc && ds < ds1;
         const int p = ds / D, n_ = ds - p * D;
         // SynchAndChanEst.py:222-223  data_ptr = tsr0 + S*L*(P+1), P = p*(S+D); guard once per pattern
         const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
-        const bool compute = sym_valid && (pat_ptr + N - 1 <= a.frame_len);
-        const int64_t start = pat_ptr + int64_t(L) * n_;            // :226 CP strip by offset
-
-        cf v[P];
-        if (compute && start + N <= a.frame_len) {
-            const cf* src = frame_iq + start + t;
+        si.compute = si.valid && (pat_ptr + N - 1 <= a.frame_len);
+        si.start = pat_ptr + int64_t(L) * n_;                        // :226 CP strip by offset
+        si.row = p * a.row_stride_pat + n_;
+        return si;
+    };
+    auto load_symbol = [&](const SymInfo& si, cf (&v)[P]) {
+        if (si.compute && si.start + N <= a.frame_len) {
+            const cf* src = frame_iq + si.start + t;
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) v[n0] = src[T * n0];
         } else {
+            const int64_t last = a.frame_len > 0 ? a.frame_len - 1 : 0;
+            const bool any = si.compute && a.frame_len > 0;
 #pragma unroll
-            for (int n0 = 0; n0 < P; ++n0) {
-                const int64_t idx = start + t + T * n0;              // short tail: fft(x, N) zero-pads (:230)
-                v[n0] = (compute && idx < a.frame_len) ? frame_iq[idx] : cf{0.f, 0.f};
+            for (int n0 = 0; n0 < P; ++n0) {                         // short tail: fft(x, N) zero-pads (:230)
+                const int64_t idx = si.start + t + T * n0;
+                const cf x = any ? frame_iq[idx < last ? idx : last] : cf{0.f, 0.f};
+                v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
             }
         }
+    };
+
+    // Register double buffer: the loads of symbol it+1 are issued before the FFT of symbol it, so every
+    // workgroup keeps one whole symbol (16 KB at N=2048) in flight while it computes.
+    SymInfo cur = sym_info(0);
+    cf v[P];
+    cf vn[PREFETCH ? P : 1];
+    if constexpr (PREFETCH) load_symbol(cur, v);
+    for (int it = 0; it < a.spc; ++it) {
+        SymInfo nxt = cur;
+        if constexpr (PREFETCH) {
+            nxt = sym_info(it + 1);
+            load_symbol(nxt, vn);
+        } else {
+            cur = sym_info(it);
+            load_symbol(cur, v);
+        }
+        const bool sym_valid = cur.valid, compute = cur.compute;
+
         wg_fft<N>(v, lds, tw, w1tab, t);                             // :230
         wg_barrier();                                                // exchange region -> staging region
 
-        // Re-materialise Kd per symbol: keeps hipcc from hoisting the 16 per-slot membership weights and
+        // Re-materialise Kd per symbol: keeps hipcc from hoisting the 16 per-slot membership tests and
         // list offsets (loop-invariant per lane) into ~50 extra VGPRs held across the symbol loop.
         int Kd_ = Kd;
         asm volatile("" : "+s"(Kd_));
-        // stage all bins in natural order; accumulate the power of the Kd listed data bins (:232-233)
+        // :232-233 gather the Kd data bins into bin-list order (lds[i]); accumulate their power
         float psum = 0.f;
+        const int hk = Kd_ >> 1;
 #pragma unroll
         for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
             for (int kl = 0; kl < PL::RL; ++kl) {
                 const int k = (t + T * j) + PL::NC * kl;
                 const cf val = v[out_slot<N>(j, kl)];
-                lds[k] = val;
-                const float w = float(int(k >= N - (Kd_ >> 1)) + int(k >= 1 && k <= (Kd_ >> 1)));   // listed twice iff Kd == N, k == N/2
-                psum += w * cnorm2(val);
+                // negative half -> i = k-(N-Kd/2); positive half -> i = Kd/2+k-1; unlisted bins fall past the list
+                // (i in [Kd, N-1]) and DC is parked at N-1, so the scatter needs no branch
+                const bool neg = k >= N - hk;
+                const bool listed = neg || (k >= 1 && k <= hk);
+                const int i = neg ? k - (N - hk) : (k == 0 ? N - 1 : hk + k - 1);
+                lds[i] = val;
+                psum += listed ? cnorm2(val) : 0.f;
+            }
+        }
+        if (Kd_ == N) {                                              // K == N lists bin N/2 twice (ofdm_chain.py:83 wiring)
+#pragma unroll
+            for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+                for (int kl = 0; kl < PL::RL; ++kl) {
+                    const int k = (t + T * j) + PL::NC * kl;
+                    if (k == N / 2) {
+                        lds[N - 1] = v[out_slot<N>(j, kl)];
+                        psum += cnorm2(v[out_slot<N>(j, kl)]);
+                    }
+                }
             }
         }
         psum = lanes_sum<T>(psum);
@@ -146,8 +197,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, Demo
         }
         const float scale = sqrtf(float(Kd_) / psum);                // :233 p_est0
 
-        const int row = p * a.row_stride_pat + n_;
-        const int64_t orow = int64_t(frame) * a.rows_per_frame + row;
+        const int64_t orow = int64_t(frame) * a.rows_per_frame + cur.row;
         if (sym_valid && (compute || a.zero_skipped)) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
@@ -167,11 +217,12 @@ __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, Demo
                         gq[2] = cf{g23.x, g23.y};
                         gq[3] = cf{g23.z, g23.w};
                     }
+                    const float4 x01 = *reinterpret_cast<const float4*>(lds + idx);
+                    const float4 x23 = four ? *reinterpret_cast<const float4*>(lds + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
+                    const cf x[4] = {cf{x01.x, x01.y}, cf{x01.z, x01.w}, cf{x23.x, x23.y}, cf{x23.z, x23.w}};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {                    // :232 bin-list order, :235-248 x*p_est0 * e^{j..} * gain
-                        const cf x = lds[list_to_bin(min(idx + e, Kd_ - 1), Kd_, N)];
-                        z[e] = compute ? cmul(cscale(x, scale), gq[e]) : cf{0.f, 0.f};
-                    }
+                    for (int e = 0; e < 4; ++e)                      // :235-248  x*p_est0 * e^{j..} * gain
+                        z[e] = compute ? cmul(cscale(x[e], scale), gq[e]) : cf{0.f, 0.f};
                     if (a.eq) {
                         float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd + idx);
                         o[0] = float4{z[0].x, z[0].y, z[1].x, z[1].y};
@@ -209,6 +260,11 @@ __global__ void __launch_bounds__(Plan<N>::WG, 3) rx_demod_kernel(RxDev rx, Demo
             }
         }
         wg_barrier();                                                // staging region free for the next symbol
+        if constexpr (PREFETCH) {
+            cur = nxt;
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) v[n0] = vn[n0];
+        }
     }
 }
 
@@ -525,7 +581,22 @@ static hipError_t launch_demod_n(const RxDev& rx, const DemodArgs& a, hipStream_
     const unsigned grid = unsigned((chunks + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
     if (grid == 0) return hipSuccess;
     const size_t lds = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * ((rx.Kd + 1) & ~1) * sizeof(cf);
-    hipLaunchKernelGGL((rx_demod_kernel<N, 2>), dim3(grid), dim3(Plan<N>::WG), lds, s, rx, a);
+#define OFDM_LAUNCH_DEMOD(G, PF, MW) \
+    hipLaunchKernelGGL((rx_demod_kernel<N, G, PF, MW>), dim3(grid), dim3(Plan<N>::WG), lds, s, rx, a)
+    if constexpr (N == 2048) {   // tuning variants (ofdm_rx_set_variant), measured in DESIGN.md
+        switch (a.variant) {
+            case 1: OFDM_LAUNCH_DEMOD(2, true, 3); break;
+            case 2: OFDM_LAUNCH_DEMOD(2, true, 2); break;
+            case 3: OFDM_LAUNCH_DEMOD(2, false, 4); break;
+            case 4: OFDM_LAUNCH_DEMOD(1, false, 2); break;
+            case 5: OFDM_LAUNCH_DEMOD(1, true, 2); break;
+            case 6: OFDM_LAUNCH_DEMOD(2, false, 2); break;
+            default: OFDM_LAUNCH_DEMOD(2, false, 3); break;
+        }
+    } else {
+        OFDM_LAUNCH_DEMOD(2, false, 3);
+    }
+#undef OFDM_LAUNCH_DEMOD
     return hipGetLastError();
 }
 template <int N>
