@@ -26,16 +26,18 @@
 
 namespace ofdm {
 
-struct alignas(8) cf {
-    float x, y;
-};
+// A complex sample is a native 2-vector: + - * map 1:1 onto v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 and the
+// .yx / .xx / .yy swizzles and sign flips fold into those instructions' op_sel / neg modifiers.  (Built with
+// -fno-slp-vectorize: left to itself hipcc's SLP pass pairs unrelated scalars and pays ~340 v_mov per symbol.)
+typedef float cf __attribute__((ext_vector_type(2)));
 
-OFDM_HD cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
-OFDM_HD cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
-OFDM_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-OFDM_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a*conj(b)
+OFDM_HD cf pk_fma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+// a*b = a*(b.x,b.x) + (a.y,a.x)*(-b.y,b.y)
+OFDM_HD cf cmul(cf a, cf b) { return pk_fma(a.yx, cf{-b.y, b.y}, a * b.xx); }
+// a*conj(b) = a*(b.x,b.x) + (a.y,a.x)*(b.y,-b.y)
+OFDM_HD cf cmulc(cf a, cf b) { return pk_fma(a.yx, cf{b.y, -b.y}, a * b.xx); }
 OFDM_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
-OFDM_HD cf cscale(cf a, float s) { return cf{a.x * s, a.y * s}; }
+OFDM_HD cf cscale(cf a, float s) { return a * s; }
 OFDM_HD float cnorm2(cf a) { return a.x * a.x + a.y * a.y; }
 
 // cos/sin(2*pi*j/16), j = 0..7
@@ -51,17 +53,17 @@ OFDM_HD cf mul_w(cf d) {
     if constexpr (J == 0) {
         return d;
     } else if constexpr (4 * J == R) {
-        return cf{d.y, -d.x};
+        return cf{d.y, -d.x};                                   // * -j
     } else if constexpr (8 * J == R) {
-        constexpr float c = 0.70710678118654752f;
-        return cf{(d.x + d.y) * c, (d.y - d.x) * c};
+        constexpr float c = 0.70710678118654752f;               // * (1-j)/sqrt2 : (x+y, y-x)*c
+        return (d + cf{d.y, -d.x}) * c;
     } else if constexpr (8 * J == 3 * R) {
-        constexpr float c = 0.70710678118654752f;
-        return cf{(d.y - d.x) * c, -(d.x + d.y) * c};
+        constexpr float c = 0.70710678118654752f;               // * (-1-j)/sqrt2 : (y-x, -x-y)*c
+        return (cf{d.y, -d.x} - d) * c;
     } else {
-        constexpr float c = kCos16[J * (16 / R)];
+        constexpr float c = kCos16[J * (16 / R)];               // * (c - j s) : d*c + (y,-x)*s
         constexpr float s = kSin16[J * (16 / R)];
-        return cf{d.x * c + d.y * s, d.y * c - d.x * s};
+        return pk_fma(cf{d.y, -d.x}, cf{s, s}, d * c);
     }
 }
 

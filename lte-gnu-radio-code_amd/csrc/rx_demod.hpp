@@ -1,0 +1,307 @@
+// rx_demod.hpp -- the hot kernel of the receive path (gfx950).
+//
+//   rx_demod_kernel<N, MOD, BMODE, MINW>
+//     per data symbol: CP strip (by offset) + N-point FFT + data-bin de-map + per-symbol power normalisation
+//     + lag de-rotation + one-tap MMSE equalise + (fused) hard de-map / bit packing
+//     reference: gr-utsa_ofdm/python/SynchAndChanEst.py:221-248 ("Loop B"), BitRecovery.py:105-157
+//
+// Data flow per symbol (N = 2048: T = 128 lanes = 2 waves, 16 points per lane):
+//   HBM --16 x 8 B/lane coalesced--> VGPR --radix16--> LDS A --radix16--> LDS B --radix8--> VGPR (bins, lane ~ bin)
+//   --scatter into the reference's bin-list order--> LDS --4 consecutive list entries per lane (16 B reads)-->
+//   power sum (wave shuffle + LDS) --> x * sqrt(Kd/P) * gain[i] --> 16 B/lane stores (+ packed bits)
+// The frame's Kd gains (equaliser * lag de-rotation, written by rx_sync_kernel) are copied into LDS once per
+// chunk of symbols.  A symbol is read from HBM once and written once: the kernel is HBM-bound by design,
+// everything else is about keeping the VALU/LDS instruction stream short enough to stay under that bound.
+//
+// MOD   bits per symbol of the fused de-mapper (1,2,4,6)           } compile-time: the per-element
+// BMODE 0 = no bits, 1 = packed MSB-first, 2 = one bit per byte      } decision code has no runtime switches
+// MINW  __launch_bounds__ min waves per SIMD (register budget; 3 -> 168 VGPRs)
+#pragma once
+#include "ofdm_launch.hpp"
+
+namespace ofdm {
+
+// BitRecovery's hard decision for float32 inputs (oracle/ofdm_oracle.py:demap_hard has the derivation):
+//   QPSK axis bit = 1  iff  -sqrt2 <= x < 0  or  x > sqrt2   ==  (x < 0) xor (|x| > sqrt2_f32)
+__device__ __forceinline__ unsigned qpsk_axis_bit(float x) {
+    constexpr float t = 1.41421354f;   // largest float32 below sqrt(2)
+    return unsigned(x < 0.f) ^ unsigned(fabsf(x) > t);
+}
+
+// bits of one symbol, b0 in the most significant of MOD bits
+template <int MOD>
+__device__ __forceinline__ unsigned hard_bits(cf z) {
+    if constexpr (MOD == 2) {
+        return (qpsk_axis_bit(z.x) << 1) | qpsk_axis_bit(z.y);
+    } else if constexpr (MOD == 1) {
+        return z.x > 0.f;
+    } else if constexpr (MOD == 4) {
+        constexpr float t = 0.63245553203367588f;   // 2/sqrt(10)
+        return (unsigned(z.x < 0.f) << 3) | (unsigned(z.y < 0.f) << 2) | (unsigned(fabsf(z.x) > t) << 1) |
+               unsigned(fabsf(z.y) > t);
+    } else {
+        constexpr float a = 0.61721339984836765f;    // 4/sqrt(42)
+        constexpr float c = 0.30860669992418382f;    // 2/sqrt(42)
+        return (unsigned(z.x < 0.f) << 5) | (unsigned(z.y < 0.f) << 4) | (unsigned(fabsf(z.x) > a) << 3) |
+               (unsigned(fabsf(z.y) > a) << 2) | (unsigned(fabsf(fabsf(z.x) - a) > c) << 1) |
+               unsigned(fabsf(fabsf(z.y) - a) > c);
+    }
+}
+__device__ __forceinline__ unsigned hard_bits_rt(cf z, int mod) {
+    return mod == 2 ? hard_bits<2>(z) : mod == 1 ? hard_bits<1>(z) : mod == 4 ? hard_bits<4>(z) : hard_bits<6>(z);
+}
+
+// writes the bits of 4 (or `cnt`) consecutive list entries starting at list index idx of output row `orow`
+template <int MOD, int BMODE>
+__device__ __forceinline__ void store_bits(uint8_t* bits, int64_t sym0, const cf (&z)[4], int cnt) {
+    if constexpr (BMODE == 1) {            // packed MSB-first: 4 symbols -> MOD/2 bytes (host guarantees Kd % 4 == 0, MOD even)
+        const unsigned w = (((((hard_bits<MOD>(z[0]) << MOD) | hard_bits<MOD>(z[1])) << MOD) | hard_bits<MOD>(z[2])) << MOD) |
+                           hard_bits<MOD>(z[3]);
+        uint8_t* o = bits + sym0 * MOD / 8;
+        if constexpr (MOD == 2) {
+            o[0] = uint8_t(w);
+        } else if constexpr (MOD == 4) {
+            *reinterpret_cast<uint16_t*>(o) = uint16_t(((w & 0xffu) << 8) | (w >> 8));
+        } else {
+            o[0] = uint8_t(w >> 16);
+            o[1] = uint8_t(w >> 8);
+            o[2] = uint8_t(w);
+        }
+    } else if constexpr (BMODE == 2) {     // one bit per byte
+        uint8_t* o = bits + sym0 * MOD;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e < cnt) {
+                const unsigned hb = hard_bits<MOD>(z[e]);
+#pragma unroll
+                for (int b = 0; b < MOD; ++b) o[e * MOD + b] = uint8_t((hb >> (MOD - 1 - b)) & 1u);
+            }
+        }
+    }
+}
+
+// GLDS  true: the frame's gains are copied to LDS once per chunk; false: re-read from global memory per symbol
+// NT    true: the once-touched IQ stream is loaded / the outputs are stored with the non-temporal hint
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false>
+__global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P, Q = P / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
+
+    const int64_t chunk = int64_t(blockIdx.x) * PL::SLOTS + slot;
+    const bool active = chunk < int64_t(a.n_frames) * a.chunks_per_frame;
+    const int frame = active ? int(chunk / a.chunks_per_frame) : 0;
+    const int cidx = active ? int(chunk % a.chunks_per_frame) : 0;
+    const int ds0 = cidx * a.spc;
+    const int ds1 = min(ds0 + a.spc, a.n_dsym);
+
+    LaneTwiddles<N> tw;
+    load_twiddles<N>(tw, rx.tw, t);
+
+    const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
+    const int tsr0 = active ? a.tsr[frame * 4 + 0] : 0;
+    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
+
+    // the frame's gains -> LDS, once per chunk (Kd even: whole 16 B pairs); published by the FFT's first barrier
+    const int Kd_pad = (Kd + 3) & ~3;
+    const cf* gain = a.gain + int64_t(frame) * Kd;
+    cf* glds = smem + WgLds<N>::STRIDE * PL::SLOTS + WgLds<N>::W1_ELEMS + slot * Kd_pad;
+    const cf* gsrc = GLDS ? glds : gain;
+    if constexpr (GLDS) {
+        for (int i = 2 * t; i < Kd; i += 2 * T) {
+            const float4 gg = active ? *reinterpret_cast<const float4*>(gain + i) : float4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<float4*>(glds + i) = gg;
+        }
+    }
+
+    for (int it = 0; it < a.spc; ++it) {
+        const int ds = ds0 + it;
+        const bool sym_valid = active && ds < ds1;
+        const int p = ds / D, n_ = ds - p * D;
+        // SynchAndChanEst.py:222-223  data_ptr = tsr0 + S*L*(P+1), P = p*(S+D); guard once per pattern
+        const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
+        const bool compute = sym_valid && (pat_ptr + N - 1 <= a.frame_len);
+        const int64_t start = pat_ptr + int64_t(L) * n_;                 // :226 CP strip by offset
+        const int64_t orow = int64_t(frame) * a.rows_per_frame + (p * a.row_stride_pat + n_);
+
+        cf v[P];
+        if (compute && start + N <= a.frame_len) {
+            const cf* src = frame_iq + start + t;
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) v[n0] = NT ? __builtin_nontemporal_load(src + T * n0) : src[T * n0];
+        } else {                                                         // short tail: fft(x, N) zero-pads (:230)
+            const int64_t last = a.frame_len > 0 ? a.frame_len - 1 : 0;
+            const bool any = compute && a.frame_len > 0;
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) {
+                const int64_t idx = start + t + T * n0;
+                const cf x = any ? frame_iq[idx < last ? idx : last] : cf{0.f, 0.f};
+                v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
+            }
+        }
+        wg_fft<N>(v, lds, tw, w1tab, t);                                 // :230
+        wg_barrier();                                                    // exchange region -> staging region
+
+        // Re-materialise Kd per symbol so hipcc does not hoist 16 per-slot list offsets into VGPRs held across the loop.
+        int Kd_ = Kd;
+        asm volatile("" : "+s"(Kd_));
+        const int hk = Kd_ >> 1;
+        // :232 gather into bin-list order: negative half i = k-(N-Kd/2), positive half i = Kd/2+k-1.
+        // Unlisted bins fall past the list (i in [Kd, N-2]) and DC is parked at index N (< LDS_ELEMS): no branches.
+        const int off_neg = hk - N, off_pos = hk - 1;
+#pragma unroll
+        for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+            for (int kl = 0; kl < PL::RL; ++kl) {
+                const int k = (t + T * j) + PL::NC * kl;
+                int i = k + ((k >= N - hk) ? off_neg : off_pos);
+                if (j == 0 && kl == 0) i = (k == 0) ? N : i;             // only this slot can hold DC
+                lds[i] = v[out_slot<N>(j, kl)];
+            }
+        }
+        if (Kd_ == N) {                                                  // K == N lists bin N/2 twice (ofdm_chain.py:83 wiring)
+#pragma unroll
+            for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+                for (int kl = 0; kl < PL::RL; ++kl)
+                    if ((t + T * j) + PL::NC * kl == N / 2) lds[N - 1] = v[out_slot<N>(j, kl)];
+            }
+        }
+        wg_barrier();
+
+        // each lane owns 4 consecutive list entries per q: 16 B LDS reads, 16 B global stores
+        cf x[Q][4];
+        float psum = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int idx = 4 * (t + T * q);
+            const float4 a01 = *reinterpret_cast<const float4*>(lds + idx);
+            const float4 a23 = *reinterpret_cast<const float4*>(lds + idx + 2);
+            x[q][0] = cf{a01.x, a01.y};
+            x[q][1] = cf{a01.z, a01.w};
+            x[q][2] = cf{a23.x, a23.y};
+            x[q][3] = cf{a23.z, a23.w};
+            if (4 * T * (q + 1) <= Kd_) {                                // whole wavefront row inside the list (uniform)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) psum += cnorm2(x[q][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) psum += (idx + e < Kd_) ? cnorm2(x[q][e]) : 0.f;
+            }
+        }
+        psum = lanes_sum<T>(psum);                                       // :233 sum |x|^2 over the Kd listed bins
+        if constexpr (T > 64) {
+            if ((t & 63) == 0) red[t >> 6] = psum;
+            wg_barrier();
+            psum = 0.f;
+#pragma unroll
+            for (int w = 0; w < T / 64; ++w) psum += red[w];
+        }
+        const float scale = sqrtf(float(Kd_) / psum);                    // :233 p_est0
+
+        if (compute) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int idx = 4 * (t + T * q);
+                if (idx < Kd_) {
+                    const bool four = idx + 2 < Kd_;
+                    const float4 g01 = *reinterpret_cast<const float4*>(gsrc + idx);
+                    const float4 g23 = (GLDS || four) ? *reinterpret_cast<const float4*>(gsrc + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
+                    cf z[4];                                             // :235-248  x * p_est0 * e^{j..} * gain
+                    z[0] = cmul(cscale(x[q][0], scale), cf{g01.x, g01.y});
+                    z[1] = cmul(cscale(x[q][1], scale), cf{g01.z, g01.w});
+                    z[2] = cmul(cscale(x[q][2], scale), cf{g23.x, g23.y});
+                    z[3] = cmul(cscale(x[q][3], scale), cf{g23.z, g23.w});
+                    if (a.eq) {
+                        float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx);
+                        const float4 o0 = float4{z[0].x, z[0].y, z[1].x, z[1].y}, o1 = float4{z[2].x, z[2].y, z[3].x, z[3].y};
+                        if constexpr (NT) {
+                            typedef float f4 __attribute__((ext_vector_type(4)));
+                            f4* on = reinterpret_cast<f4*>(o);
+                            __builtin_nontemporal_store(f4{o0.x, o0.y, o0.z, o0.w}, on);
+                            if (four) __builtin_nontemporal_store(f4{o1.x, o1.y, o1.z, o1.w}, on + 1);
+                        } else {
+                            o[0] = o0;
+                            if (four) o[1] = o1;
+                        }
+                    }
+                    if constexpr (BMODE != 0) store_bits<MOD, BMODE>(a.bits, orow * Kd_ + idx, z, four ? 4 : 2);
+                }
+            }
+        } else if (sym_valid && a.zero_skipped) {                        // pattern guard failed: defined (zero) output
+            const cf zz[4] = {cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int idx = 4 * (t + T * q);
+                if (idx < Kd_) {
+                    const bool four = idx + 2 < Kd_;
+                    if (a.eq) {
+                        float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx);
+                        o[0] = float4{0.f, 0.f, 0.f, 0.f};
+                        if (four) o[1] = float4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if constexpr (BMODE != 0) store_bits<MOD, BMODE>(a.bits, orow * Kd_ + idx, zz, four ? 4 : 2);
+                }
+            }
+        }
+        wg_barrier();                                                    // staging region free for the next symbol
+    }
+}
+
+// one translation unit per FFT size instantiates this (rx_demod_<N>.hip)
+template <int N>
+hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a, hipStream_t s) {
+    const int64_t chunks = int64_t(a.n_frames) * a.chunks_per_frame;
+    const unsigned grid = unsigned((chunks + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    if (grid == 0) return hipSuccess;
+    const size_t lds_g = size_t(Plan<N>::SLOTS) * ((rx.Kd + 3) & ~3) * sizeof(cf);
+    size_t lds = WgLds<N>::BYTES + lds_g;
+    const int bmode = a.bits ? a.bits_mode : 0;
+    if constexpr (N == 2048) {      // tuning variants (ofdm_rx_set_variant): 16-QAM packed only
+        if (a.variant != 0 && bmode == 1 && a.mod == 4) {
+            if (a.variant == 1) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, true>), dim3(grid), dim3(Plan<N>::WG), lds, s, rx, a);
+            if (a.variant == 2) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, true>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
+            if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, false>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
+            if (a.variant == 4) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 4, false, true>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
+            return hipGetLastError();
+        }
+    }
+#define OFDM_LD(M, B) \
+    hipLaunchKernelGGL((rx_demod_kernel<N, M, B, 3>), dim3(grid), dim3(Plan<N>::WG), lds, s, rx, a)
+#define OFDM_LD_MOD(B)                  \
+    switch (a.mod) {                    \
+        case 1: OFDM_LD(1, B); break;   \
+        case 2: OFDM_LD(2, B); break;   \
+        case 4: OFDM_LD(4, B); break;   \
+        default: OFDM_LD(6, B); break;  \
+    }
+    if (bmode == 0) {
+        OFDM_LD(2, 0);
+    } else if (bmode == 1) {
+        OFDM_LD_MOD(1)
+    } else {
+        OFDM_LD_MOD(2)
+    }
+#undef OFDM_LD_MOD
+#undef OFDM_LD
+    return hipGetLastError();
+}
+
+#define OFDM_DECLARE_DEMOD(n) hipError_t launch_rx_demod_##n(const RxDev& rx, const DemodArgs& a, hipStream_t s);
+OFDM_DECLARE_DEMOD(64)
+OFDM_DECLARE_DEMOD(128)
+OFDM_DECLARE_DEMOD(256)
+OFDM_DECLARE_DEMOD(512)
+OFDM_DECLARE_DEMOD(1024)
+OFDM_DECLARE_DEMOD(2048)
+OFDM_DECLARE_DEMOD(4096)
+#undef OFDM_DECLARE_DEMOD
+
+}  // namespace ofdm

@@ -1,0 +1,5 @@
+// rx_demod_128.hip -- instantiates rx_demod_kernel<128, ...> (one translation unit per FFT size keeps the build parallel)
+#include "rx_demod.hpp"
+namespace ofdm {
+hipError_t launch_rx_demod_128(const RxDev& rx, const DemodArgs& a, hipStream_t s) { return launch_rx_demod_n<128>(rx, a, s); }
+}  // namespace ofdm

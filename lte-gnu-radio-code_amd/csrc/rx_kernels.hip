@@ -10,263 +10,9 @@
 // lanes = SLOTS symbols side by side.  A symbol is read from HBM exactly once (coalesced, CP skipped
 // by offset), lives in VGPRs/LDS through the FFT, and leaves as one coalesced 16 B/lane store of
 // its Kd equalised bins (+ packed bits).  No MFMA: the path is FFT + elementwise, HBM-bound.
-#include "ofdm_launch.hpp"
+#include "rx_demod.hpp"
 
 namespace ofdm {
-
-// ------------------------------------------------------------------------------------------ de-map
-// BitRecovery's hard decision for float32 inputs (see oracle/ofdm_oracle.py:demap_hard for the derivation):
-//   QPSK  b = 1  iff  -sqrt2 <= x < 0  or  x > sqrt2      (sign rule + the reference's outlier flip)
-__device__ __forceinline__ unsigned qpsk_axis_bit(float x) {
-    constexpr float t = 1.41421354f;   // largest float32 below sqrt(2)
-    return ((x < 0.f) & (x >= -t)) | (x > t);
-}
-
-// returns the symbol's bits, b0 in the most significant of `bps` bits
-__device__ __forceinline__ unsigned hard_bits(cf z, int bps) {
-    if (bps == 2) return (qpsk_axis_bit(z.x) << 1) | qpsk_axis_bit(z.y);
-    if (bps == 1) return z.x > 0.f;
-    if (bps == 4) {
-        constexpr float t = 0.63245553203367588f;   // 2/sqrt(10)
-        return ((z.x < 0.f) << 3) | ((z.y < 0.f) << 2) | ((fabsf(z.x) > t) << 1) | (fabsf(z.y) > t);
-    }
-    constexpr float a = 0.61721339984836765f;        // 4/sqrt(42)
-    constexpr float c = 0.30860669992418382f;        // 2/sqrt(42)
-    return ((z.x < 0.f) << 5) | ((z.y < 0.f) << 4) | ((fabsf(z.x) > a) << 3) | ((fabsf(z.y) > a) << 2) |
-           ((fabsf(fabsf(z.x) - a) > c) << 1) | (fabsf(fabsf(z.y) - a) > c);
-}
-
-// ------------------------------------------------------------------------------------------ data demod
-// list position i (0..Kd-1) of the reference's bins_used_P  ->  FFT bin k
-__device__ __forceinline__ int list_to_bin(int i, int K, int N) { return (i < (K >> 1)) ? N - (K >> 1) + i : i - (K >> 1) + 1; }
-
-// GMODE: where the frame's equaliser gains live while a chunk of its symbols is processed.
-//   0 = re-read from global memory for every symbol (r01 v1: the stream thrashes L2, so these 8 B/bin
-//       re-reads reach the fabric -- +35 % HBM traffic, profiles/r01_v1_pmc_traffic.json)
-//   1 = 32 VGPRs per lane (costs a wave of occupancy per SIMD)
-//   2 = a Kd-entry LDS copy per symbol slot, filled once per chunk (default)
-// PREFETCH: register double buffer -- issue the loads of symbol it+1 before the FFT of symbol it.
-// MINW: minimum waves per SIMD requested from the register allocator (__launch_bounds__ 2nd argument).
-template <int N, int GMODE, bool PREFETCH, int MINW>
-__global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
-    using PL = Plan<N>;
-    constexpr int T = PL::T, P = PL::P, Q = P / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x;
-    const int slot = tid / T;
-    const int t = tid % T;
-    cf* smem = reinterpret_cast<cf*>(smem_raw);
-    cf* lds = smem + slot * WgLds<N>::STRIDE;
-    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
-    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
-
-    const int64_t chunk = int64_t(blockIdx.x) * PL::SLOTS + slot;
-    const int64_t total_chunks = int64_t(a.n_frames) * a.chunks_per_frame;
-    const bool active = chunk < total_chunks;
-    const int frame = active ? int(chunk / a.chunks_per_frame) : 0;
-    const int cidx = active ? int(chunk % a.chunks_per_frame) : 0;
-    const int ds0 = cidx * a.spc;
-    const int ds1 = min(ds0 + a.spc, a.n_dsym);
-
-    LaneTwiddles<N> tw;
-    load_twiddles<N>(tw, rx.tw, t);
-
-    const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
-    const int tsr0 = active ? a.tsr[frame * 4 + 0] : 0;
-    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
-
-    // equaliser gains of this lane's output positions (4 consecutive list entries per q), fixed for the chunk
-    const cf* gain = a.gain + int64_t(frame) * Kd;
-    const int Kd_pad = (Kd + 1) & ~1;
-    cf* glds = smem + WgLds<N>::STRIDE * PL::SLOTS + WgLds<N>::W1_ELEMS + slot * Kd_pad;
-    if constexpr (GMODE == 2) {
-        for (int i = 2 * t; i < Kd; i += 2 * T) {      // Kd is even: whole 16 B pairs; published by the FFT's first barrier
-            const float4 gg = active ? *reinterpret_cast<const float4*>(gain + i) : float4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<float4*>(glds + i) = gg;
-        }
-    }
-    cf g[GMODE == 1 ? Q : 1][4];
-    if constexpr (GMODE == 1) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int idx = 4 * (t + T * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[q][e] = (active && idx + e < Kd) ? gain[idx + e] : cf{0.f, 0.f};
-        }
-    }
-
-    // symbol `ds` of this chunk: where its N-sample window starts and whether it is computed at all
-    struct SymInfo {
-        bool valid, compute;
-        int row;
-        int64_t start;
-    };
-    auto sym_info = [&](int it) {
-        SymInfo si;
-        const int ds = ds0 + it;
-        si.valid = active && it < a.spc && ds < ds1;
-        const int p = ds / D, n_ = ds - p * D;
-        // SynchAndChanEst.py:222-223  data_ptr = tsr0 + S*L*(P+1), P = p*(S+D); guard once per pattern
-        const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
-        si.compute = si.valid && (pat_ptr + N - 1 <= a.frame_len);
-        si.start = pat_ptr + int64_t(L) * n_;                        // :226 CP strip by offset
-        si.row = p * a.row_stride_pat + n_;
-        return si;
-    };
-    auto load_symbol = [&](const SymInfo& si, cf (&v)[P]) {
-        if (si.compute && si.start + N <= a.frame_len) {
-            const cf* src = frame_iq + si.start + t;
-#pragma unroll
-            for (int n0 = 0; n0 < P; ++n0) v[n0] = src[T * n0];
-        } else {
-            const int64_t last = a.frame_len > 0 ? a.frame_len - 1 : 0;
-            const bool any = si.compute && a.frame_len > 0;
-#pragma unroll
-            for (int n0 = 0; n0 < P; ++n0) {                         // short tail: fft(x, N) zero-pads (:230)
-                const int64_t idx = si.start + t + T * n0;
-                const cf x = any ? frame_iq[idx < last ? idx : last] : cf{0.f, 0.f};
-                v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
-            }
-        }
-    };
-
-    // Register double buffer: the loads of symbol it+1 are issued before the FFT of symbol it, so every
-    // workgroup keeps one whole symbol (16 KB at N=2048) in flight while it computes.
-    SymInfo cur = sym_info(0);
-    cf v[P];
-    cf vn[PREFETCH ? P : 1];
-    if constexpr (PREFETCH) load_symbol(cur, v);
-    for (int it = 0; it < a.spc; ++it) {
-        SymInfo nxt = cur;
-        if constexpr (PREFETCH) {
-            nxt = sym_info(it + 1);
-            load_symbol(nxt, vn);
-        } else {
-            cur = sym_info(it);
-            load_symbol(cur, v);
-        }
-        const bool sym_valid = cur.valid, compute = cur.compute;
-
-        wg_fft<N>(v, lds, tw, w1tab, t);                             // :230
-        wg_barrier();                                                // exchange region -> staging region
-
-        // Re-materialise Kd per symbol: keeps hipcc from hoisting the 16 per-slot membership tests and
-        // list offsets (loop-invariant per lane) into ~50 extra VGPRs held across the symbol loop.
-        int Kd_ = Kd;
-        asm volatile("" : "+s"(Kd_));
-        // :232-233 gather the Kd data bins into bin-list order (lds[i]); accumulate their power
-        float psum = 0.f;
-        const int hk = Kd_ >> 1;
-#pragma unroll
-        for (int j = 0; j < PL::C; ++j) {
-#pragma unroll
-            for (int kl = 0; kl < PL::RL; ++kl) {
-                const int k = (t + T * j) + PL::NC * kl;
-                const cf val = v[out_slot<N>(j, kl)];
-                // negative half -> i = k-(N-Kd/2); positive half -> i = Kd/2+k-1; unlisted bins fall past the list
-                // (i in [Kd, N-1]) and DC is parked at N-1, so the scatter needs no branch
-                const bool neg = k >= N - hk;
-                const bool listed = neg || (k >= 1 && k <= hk);
-                const int i = neg ? k - (N - hk) : (k == 0 ? N - 1 : hk + k - 1);
-                lds[i] = val;
-                psum += listed ? cnorm2(val) : 0.f;
-            }
-        }
-        if (Kd_ == N) {                                              // K == N lists bin N/2 twice (ofdm_chain.py:83 wiring)
-#pragma unroll
-            for (int j = 0; j < PL::C; ++j) {
-#pragma unroll
-                for (int kl = 0; kl < PL::RL; ++kl) {
-                    const int k = (t + T * j) + PL::NC * kl;
-                    if (k == N / 2) {
-                        lds[N - 1] = v[out_slot<N>(j, kl)];
-                        psum += cnorm2(v[out_slot<N>(j, kl)]);
-                    }
-                }
-            }
-        }
-        psum = lanes_sum<T>(psum);
-        if constexpr (T > 64) {
-            if ((t & 63) == 0) red[t >> 6] = psum;
-        }
-        wg_barrier();
-        if constexpr (T > 64) {
-            psum = 0.f;
-#pragma unroll
-            for (int w = 0; w < T / 64; ++w) psum += red[w];
-        }
-        const float scale = sqrtf(float(Kd_) / psum);                // :233 p_est0
-
-        const int64_t orow = int64_t(frame) * a.rows_per_frame + cur.row;
-        if (sym_valid && (compute || a.zero_skipped)) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int idx = 4 * (t + T * q);
-                if (idx < Kd_) {
-                    const bool four = idx + 2 < Kd_;
-                    cf z[4], gq[4];
-                    if constexpr (GMODE == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) gq[e] = g[q][e];
-                    } else {
-                        const cf* gsrc = (GMODE == 2) ? glds : gain;
-                        const float4 g01 = *reinterpret_cast<const float4*>(gsrc + idx);
-                        const float4 g23 = four ? *reinterpret_cast<const float4*>(gsrc + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
-                        gq[0] = cf{g01.x, g01.y};
-                        gq[1] = cf{g01.z, g01.w};
-                        gq[2] = cf{g23.x, g23.y};
-                        gq[3] = cf{g23.z, g23.w};
-                    }
-                    const float4 x01 = *reinterpret_cast<const float4*>(lds + idx);
-                    const float4 x23 = four ? *reinterpret_cast<const float4*>(lds + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
-                    const cf x[4] = {cf{x01.x, x01.y}, cf{x01.z, x01.w}, cf{x23.x, x23.y}, cf{x23.z, x23.w}};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)                      // :235-248  x*p_est0 * e^{j..} * gain
-                        z[e] = compute ? cmul(cscale(x[e], scale), gq[e]) : cf{0.f, 0.f};
-                    if (a.eq) {
-                        float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd + idx);
-                        o[0] = float4{z[0].x, z[0].y, z[1].x, z[1].y};
-                        if (four) o[1] = float4{z[2].x, z[2].y, z[3].x, z[3].y};
-                    }
-                    if (a.bits) {
-                        unsigned hb[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hb[e] = hard_bits(z[e], a.mod);
-                        if (a.bits_mode == 1) {                      // packed MSB-first: 4 symbols -> mod/2 bytes
-                            const unsigned w = (((((hb[0] << a.mod) | hb[1]) << a.mod) | hb[2]) << a.mod) | hb[3];
-                            uint8_t* o = a.bits + (orow * Kd + idx) * a.mod / 8;
-                            if (a.mod == 2) {
-                                o[0] = uint8_t(w);
-                            } else if (a.mod == 4) {
-                                *reinterpret_cast<uint16_t*>(o) = uint16_t(((w & 0xffu) << 8) | (w >> 8));
-                            } else {
-                                o[0] = uint8_t(w >> 16);
-                                o[1] = uint8_t(w >> 8);
-                                o[2] = uint8_t(w);
-                            }
-                        } else {                                     // one bit per byte
-                            uint8_t* o = a.bits + (orow * Kd + idx) * a.mod;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (e < 2 || four) {
-#pragma unroll
-                                    for (int b = 0; b < 6; ++b)
-                                        if (b < a.mod) o[e * a.mod + b] = uint8_t((hb[e] >> (a.mod - 1 - b)) & 1u);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        wg_barrier();                                                // staging region free for the next symbol
-        if constexpr (PREFETCH) {
-            cur = nxt;
-#pragma unroll
-            for (int n0 = 0; n0 < P; ++n0) v[n0] = vn[n0];
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------ sync
 // One sync trial P of one frame (SynchAndChanEst.py:145-164).  On return: Z (per-lane bins, register
@@ -513,7 +259,7 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
 __global__ void demap_hard_kernel(DemapArgs a) {
     const int64_t n = a.n;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const unsigned hb = hard_bits(a.sym[i], a.mod);
+        const unsigned hb = hard_bits_rt(a.sym[i], a.mod);
         for (int b = 0; b < a.mod; ++b) a.hard[i * a.mod + b] = (hb >> (a.mod - 1 - b)) & 1u;
     }
 }
@@ -576,30 +322,6 @@ __global__ void __launch_bounds__(256) demap_soft_kernel(DemapArgs a) {
 
 // ------------------------------------------------------------------------------------------ launchers
 template <int N>
-static hipError_t launch_demod_n(const RxDev& rx, const DemodArgs& a, hipStream_t s) {
-    const int64_t chunks = int64_t(a.n_frames) * a.chunks_per_frame;
-    const unsigned grid = unsigned((chunks + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
-    if (grid == 0) return hipSuccess;
-    const size_t lds = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * ((rx.Kd + 1) & ~1) * sizeof(cf);
-#define OFDM_LAUNCH_DEMOD(G, PF, MW) \
-    hipLaunchKernelGGL((rx_demod_kernel<N, G, PF, MW>), dim3(grid), dim3(Plan<N>::WG), lds, s, rx, a)
-    if constexpr (N == 2048) {   // tuning variants (ofdm_rx_set_variant), measured in DESIGN.md
-        switch (a.variant) {
-            case 1: OFDM_LAUNCH_DEMOD(2, true, 3); break;
-            case 2: OFDM_LAUNCH_DEMOD(2, true, 2); break;
-            case 3: OFDM_LAUNCH_DEMOD(2, false, 4); break;
-            case 4: OFDM_LAUNCH_DEMOD(1, false, 2); break;
-            case 5: OFDM_LAUNCH_DEMOD(1, true, 2); break;
-            case 6: OFDM_LAUNCH_DEMOD(2, false, 2); break;
-            default: OFDM_LAUNCH_DEMOD(2, false, 3); break;
-        }
-    } else {
-        OFDM_LAUNCH_DEMOD(2, false, 3);
-    }
-#undef OFDM_LAUNCH_DEMOD
-    return hipGetLastError();
-}
-template <int N>
 static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
     const int64_t units = (a.mode == 1) ? a.p_count : a.n_frames;
     const unsigned grid = unsigned((units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
@@ -621,7 +343,7 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
     }
 
 hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s) {
-#define CALL(n) launch_demod_n<n>(rx, a, s)
+#define CALL(n) launch_rx_demod_##n(rx, a, s)
     OFDM_DISPATCH_N(rx.nfft, CALL)
 #undef CALL
 }

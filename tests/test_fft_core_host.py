@@ -17,7 +17,7 @@ def exe(tmp_path_factory):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     out = str(tmp_path_factory.mktemp("fftcore") / "fft_core_host_test")
-    subprocess.run(["hipcc", "-O2", "-std=c++17", "-o", out, SRC], check=True)
+    subprocess.run(["hipcc", "-O2", "-std=c++17", "-fno-slp-vectorize", "-o", out, SRC], check=True)
     return out
 
 

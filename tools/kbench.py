@@ -8,7 +8,7 @@ import numpy as np, torch
 import ofdm_mi355x as om
 import bench
 
-variants = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6]
+variants = [int(x) for x in sys.argv[1:]] or [0]
 cfg = dict(bench.CONFIGS[os.environ.get("KB_CONFIG", "cfg2")])
 n_frames = int(os.environ.get("KB_FRAMES", "2048"))
 torch.cuda.set_device(0)
