@@ -41,6 +41,7 @@ class _Mark:
 _ALLOWED = {
     "numpy.core.multiarray _reconstruct", "numpy._core.multiarray _reconstruct",
     "numpy ndarray", "numpy dtype", "_codecs encode",
+    "numpy.core.numeric _frombuffer", "numpy._core.numeric _frombuffer",      # protocol-5 ndarray pickles
 }
 _DTYPES = {"c16", "c8", "f8", "f4", "i8", "i4", "i2", "i1", "u8", "u4", "u2", "u1", "b1"}
 
@@ -50,6 +51,13 @@ def _reduce(fn, args):
         raise UnsafePickleError("REDUCE on a non-whitelisted callable")
     if fn.name.endswith("_reconstruct"):
         return _Array()
+    if fn.name.endswith("_frombuffer"):
+        if not (isinstance(args, tuple) and len(args) == 4 and isinstance(args[0], (bytes, bytearray))
+                and isinstance(args[1], _DType) and isinstance(args[2], tuple) and args[3] in ("C", "F")):
+            raise UnsafePickleError("unexpected _frombuffer arguments")
+        arr = _Array()
+        arr.state = (1, args[2], args[1], args[3] == "F", bytes(args[0]))
+        return arr
     if fn.name == "numpy dtype":
         if not (isinstance(args, tuple) and args and isinstance(args[0], str) and args[0] in _DTYPES):
             raise UnsafePickleError("dtype %r not allowed" % (args,))
@@ -81,7 +89,7 @@ def loads_ndarray(data: bytes) -> np.ndarray:
                 raise UnsafePickleError("global %r not allowed" % full)
             stack.append(_Global(full))
         elif n in ("BININT", "BININT1", "BININT2", "LONG1", "BINUNICODE", "SHORT_BINUNICODE",
-                   "BINUNICODE8", "BINBYTES", "SHORT_BINBYTES", "BINBYTES8"):
+                   "BINUNICODE8", "BINBYTES", "SHORT_BINBYTES", "BINBYTES8", "BYTEARRAY8"):
             stack.append(arg)
         elif n in ("BINSTRING", "SHORT_BINSTRING"):       # python-2 era raw str payloads
             stack.append(arg.encode("latin1") if isinstance(arg, str) else arg)

@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU and exports every function include/ofdm_mi355x.h declares,
+the ctypes prototype table covers exactly that set, and compute calls fail loudly (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ofdm_mi355x.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(ofdm_[a-z0-9_]+)\s*\(", txt))
+
+
+def test_library_exports_the_whole_header():
+    import ofdm_mi355x
+    from ofdm_mi355x import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built (run __graft_entry__.build())")
+    lib = ofdm_mi355x.load()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_lib.PROTOTYPES) == declared
+    assert lib.ofdm_abi_version() == 1
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    import ofdm_mi355x
+    from ofdm_mi355x import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ofdm_mi355x.OfdmError):
+        ofdm_mi355x.RxEngine(8, 64, 16, 62, (1, 3), 60, 100)       # no device -> error, never a NumPy path
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ofdm_mi355x import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.OfdmLibraryError):
+        _lib.load()
+
+
+def test_safe_pickle_rejects_code_execution(tmp_path):
+    import pickle
+    import numpy as np
+    from ofdm_mi355x.safe_pickle import UnsafePickleError, load_ndarray, loads_ndarray
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned",))
+
+    with pytest.raises(UnsafePickleError):
+        loads_ndarray(pickle.dumps(Evil()))
+    with pytest.raises(UnsafePickleError):
+        loads_ndarray(pickle.dumps({"a": 1}))
+    for proto in (2, 3, 4, 5):
+        a = (np.arange(12).reshape(3, 4) * (1 + 2j)).astype(np.complex128)
+        p = tmp_path / ("a%d.pckl" % proto)
+        p.write_bytes(pickle.dumps(a, protocol=proto))
+        assert np.array_equal(load_ndarray(str(p)), a)
+    f = np.asfortranarray(np.arange(6, dtype=np.int32).reshape(2, 3))
+    assert np.array_equal(loads_ndarray(pickle.dumps(f, protocol=2)), f)

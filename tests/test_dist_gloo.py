@@ -1,0 +1,83 @@
+"""N>1 path on CPU: 2 gloo ranks, frame shards + sub-batched all-gather of the packed bit-stream.
+The per-rank bits come from the CPU oracle here (the HIP path needs a GPU); what is tested is the sharding /
+re-assembly bookkeeping bench.py uses with RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ofdm_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_bits(frame_index):
+    """packed hard bits of one frame, deterministic in the GLOBAL frame index"""
+    N, cp, Kd, n_sym = 64, 16, 60, 8
+    rng = np.random.default_rng(1000 + frame_index)
+    bits = rng.integers(0, 2, 6 * Kd * 2)
+    iq = orc.tx_modulate(bits, N, cp, N - 2, Kd, n_sym).astype(np.complex64)
+    rx = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 100, 0.7)
+    rx.work(iq, np.zeros(len(iq), np.complex64))
+    rows = [r for r in range(n_sym) if r % 4 != 3]
+    hb = orc.demap_hard(rx.est_data_freq[rows].ravel(), "QPSK")
+    assert np.array_equal(hb, bits)
+    return np.packbits(hb)
+
+
+def _worker(rank, world, port, n_total, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "lte-gnu-radio-code_amd")]
+    from ofdm_mi355x import dist as od
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, n = od.shard_frames(n_total, world, rank)
+    local = torch.from_numpy(np.stack([_rank_bits(first + f) for f in range(n)]))
+    gathered = torch.zeros((world, n, local.shape[1]), dtype=torch.uint8)
+    works = [od.all_gather_bits(dist, gathered, local, f0, f1, async_op=True) for f0, f1 in od.sub_batches(n, 3)]
+    for w in works:
+        w.wait()
+    dist.barrier()
+    q.put((rank, gathered.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_allgather():
+    world, n_total = 2, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.stack([_rank_bits(f) for f in range(n_total)]).reshape(world, n_total // world, -1)
+    for r in range(world):
+        assert np.array_equal(res[r], expect)          # every rank holds the whole re-assembled stream, in frame order
+
+
+def test_shard_helpers():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "lte-gnu-radio-code_amd")]
+    from ofdm_mi355x import dist as od
+    assert od.shard_frames(16, 8, 3) == (6, 2)
+    with pytest.raises(ValueError):
+        od.shard_frames(10, 4, 0)
+    assert od.sub_batches(10, 4) == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    assert od.sub_batches(2, 4) == [(0, 1), (1, 2)]
