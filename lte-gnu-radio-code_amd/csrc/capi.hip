@@ -368,12 +368,8 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
         da.bits_mode = bits_mode;
         da.mod = d.bps;
         da.n_dsym = int(n_dsym);
-        const int64_t total = n_frames * n_dsym;
-        int64_t spc = total / 16384;
-        if (spc < 1) spc = 1;
-        if (spc > n_dsym) spc = n_dsym;
-        da.spc = int(spc);
-        da.chunks_per_frame = int((n_dsym + spc - 1) / spc);
+        da.spc = 0;                 // launcher picks the chunking (multiples of its slots per workgroup)
+        da.chunks_per_frame = 0;
         da.row_stride_pat = d.D;
         da.rows_per_frame = int(n_dsym);
         da.zero_skipped = 1;
@@ -549,8 +545,8 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         da.bits_mode = 0;
         da.mod = d.bps;
         da.n_dsym = int(p_ok * D);
-        da.spc = 1;
-        da.chunks_per_frame = da.n_dsym;
+        da.spc = 0;
+        da.chunks_per_frame = 0;
         da.row_stride_pat = SD;
         da.rows_per_frame = h->cfg.num_ofdm_symb;
         da.zero_skipped = 0;
