@@ -34,7 +34,7 @@ CONFIGS = {
     "cfg2": dict(nfft=2048, cp=144, Kd=1200, mod="16QAM", n_sym=240, frames=4369, chan="awgn", snr_db=30.0,
                  name="2048-pt FFT / 144-CP / Kd=1200 / 16-QAM, 4369 frames x 240 symbols (1,048,560 symbols), AWGN loopback"),
     # configs[2]
-    "cfg3": dict(nfft=2048, cp=144, Kd=1200, mod="64QAM", n_sym=240, frames=4369, chan="rayleigh", snr_db=30.0,
+    "cfg3": dict(nfft=2048, cp=144, Kd=1200, mod="64QAM", n_sym=240, frames=4369, chan="rayleigh", snr_db=30.0, gate=0.3,
                  name="2048-pt FFT / 144-CP / Kd=1200 / 64-QAM, Rayleigh 8-tap per-frame fading + AWGN 30 dB"),
     # configs[0] shape (the reference's own CPU-runnable case), scaled up in frame count
     "cfgA": dict(nfft=64, cp=16, Kd=60, mod="QPSK", n_sym=240, frames=65536, chan="ref5tap", snr_db=100.0,
@@ -105,6 +105,16 @@ def cpu_baseline(cfg, iq_host):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+class _Shift:
+    """rehearsal helper: presents a host copy of rows [f0,f1) under the indices of the full tensor"""
+
+    def __init__(self, t, f0):
+        self.t, self.f0 = t, f0
+
+    def __getitem__(self, sl):
+        return self.t[sl.start - self.f0:sl.stop - self.f0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +129,7 @@ def main():
 
     import torch
     import ofdm_mi355x as om
+    from ofdm_mi355x import dist as od
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,11 +137,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
+    # BENCH_REHEARSAL=1: rehearse the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices, the
+    # all-gather goes through gloo on host copies).  Never used for reported numbers.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     device = torch.cuda.current_device()
@@ -143,30 +161,33 @@ def main():
     bps = BPS[mod]
 
     d_rx, tx_bits = build_inputs(torch, om, cfg, n_frames, device, seed=20260101 + rank)
-    rxe = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, cfg["snr_db"], 0.7, modulation=mod, device=device)
+    rxe = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, cfg["snr_db"], cfg.get("gate", 0.7), modulation=mod, device=device)
     rxe.reserve(n_frames)
+    rxe.set_max_trials(L)     # frames are generated aligned: never scan more than one symbol period for the sync
     rxe.set_profiling(True)
     nds = rxe.data_symbols_per_frame(fl)
     bytes_per_frame_bits = nds * Kd * bps // 8
     d_eq = None if args.no_eq else torch.empty((n_frames, nds, Kd, 2), dtype=torch.float32, device="cuda")
     d_bits = torch.empty((n_frames, bytes_per_frame_bits), dtype=torch.uint8, device="cuda")
-    gathered = torch.empty((world, n_frames, bytes_per_frame_bits), dtype=torch.uint8, device="cuda") if world > 1 else None
+    gathered = None
     stream = torch.cuda.current_stream().cuda_stream
 
-    n_chunks = max(1, min(args.chunks, n_frames)) if world > 1 else 1
-    bounds = [(i * n_frames // n_chunks, (i + 1) * n_frames // n_chunks) for i in range(n_chunks)]
+    bounds = od.sub_batches(n_frames, args.chunks if world > 1 else 1)
+    n_chunks = len(bounds)
+    if world > 1:
+        gathered = od.alloc_gather_buffers(torch, world, bounds, bytes_per_frame_bits, "cpu" if rehearsal else "cuda")
     k_sync, k_demod = [], []
 
     def step(timed=False):
         works = []
-        for (f0, f1) in bounds:
+        for ci, (f0, f1) in enumerate(bounds):
             nf = f1 - f0
             rxe.demod_frames(d_rx[f0:f1], nf, fl, fl, None if d_eq is None else d_eq[f0:f1], d_bits[f0:f1],
                              om.BITS_PACKED, None, stream)
             if world > 1:
                 # equal counts per rank; rank r's frames [f0,f1) land at gathered[r, f0:f1]
-                outs = [gathered[r, f0:f1] for r in range(world)]
-                works.append(dist.all_gather(outs, d_bits[f0:f1], async_op=True))
+                src = _Shift(d_bits[f0:f1].cpu(), f0) if rehearsal else d_bits
+                works.append(od.all_gather_bits(dist, gathered[ci], src, f0, f1, async_op=True))
         for w in works:
             w.wait()
 
@@ -189,7 +210,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -204,7 +225,7 @@ def main():
         txb = tx_bits[0].cpu().numpy()
         ber = float(np.unpackbits(rxb ^ txb).sum()) / (len(rxb) * 8)
         if world > 1:
-            assert torch.equal(gathered[0], d_bits), "all-gather did not reassemble rank 0's own shard"
+            assert torch.equal(od.reassemble(torch, gathered, world)[0].cpu(), d_bits.cpu()), "all-gather did not reassemble rank 0's own shard"
 
     out = None
     if rank == 0:

@@ -21,9 +21,19 @@ def sub_batches(n_frames: int, n_chunks: int):
     return [(i * n_frames // n_chunks, (i + 1) * n_frames // n_chunks) for i in range(n_chunks)]
 
 
-def all_gather_bits(dist, gathered, local_bits, f0: int, f1: int, async_op: bool = True):
-    """Gather rows [f0,f1) of every rank's `local_bits` [n_frames, bytes] into gathered[rank, f0:f1].
+def alloc_gather_buffers(torch, world: int, bounds, row_bytes: int, device):
+    """One contiguous [world, n_rows, row_bytes] receive buffer per sub-batch: all_gather_into_tensor then needs no
+    staging copy (a list of strided views would make c10d gather into a temporary and copy out)."""
+    # 2-D [world*n_rows, row_bytes]: the concatenation-along-dim-0 form every c10d backend accepts
+    return [torch.empty((world * (f1 - f0), row_bytes), dtype=torch.uint8, device=device) for f0, f1 in bounds]
+
+
+def all_gather_bits(dist, recv, local_bits, f0: int, f1: int, async_op: bool = True):
+    """Gather rows [f0,f1) of every rank's `local_bits` [n_frames, row_bytes] into recv ([world*(f1-f0), row_bytes], rank-major).
     Returns the work handle (or None)."""
-    world = gathered.shape[0]
-    outs = [gathered[r, f0:f1] for r in range(world)]
-    return dist.all_gather(outs, local_bits[f0:f1], async_op=async_op)
+    return dist.all_gather_into_tensor(recv, local_bits[f0:f1].contiguous(), async_op=async_op)
+
+
+def reassemble(torch, recv_list, world: int):
+    """[world, n_frames, row_bytes] copy of the whole bit-stream from the per-sub-batch receive buffers."""
+    return torch.cat([r.view(world, r.shape[0] // world, r.shape[1]) for r in recv_list], dim=1)

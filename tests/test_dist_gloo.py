@@ -45,12 +45,13 @@ def _worker(rank, world, port, n_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     first, n = od.shard_frames(n_total, world, rank)
     local = torch.from_numpy(np.stack([_rank_bits(first + f) for f in range(n)]))
-    gathered = torch.zeros((world, n, local.shape[1]), dtype=torch.uint8)
-    works = [od.all_gather_bits(dist, gathered, local, f0, f1, async_op=True) for f0, f1 in od.sub_batches(n, 3)]
+    bounds = od.sub_batches(n, 3)
+    recv = od.alloc_gather_buffers(torch, world, bounds, local.shape[1], "cpu")
+    works = [od.all_gather_bits(dist, recv[i], local, f0, f1, async_op=True) for i, (f0, f1) in enumerate(bounds)]
     for w in works:
         w.wait()
     dist.barrier()
-    q.put((rank, gathered.numpy().copy()))
+    q.put((rank, od.reassemble(torch, recv, world).numpy().copy()))
     dist.destroy_process_group()
 
 
