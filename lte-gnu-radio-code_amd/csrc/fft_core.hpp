@@ -40,6 +40,30 @@ OFDM_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
 OFDM_HD cf cscale(cf a, float s) { return a * s; }
 OFDM_HD float cnorm2(cf a) { return a.x * a.x + a.y * a.y; }
 
+// In-place a_i *= b_i for three independent pairs.  hipcc cannot fold the per-lane sign of a complex product into the
+// packed instruction's neg_lo/neg_hi bits (it materialises (-b.y, b.y) with v_mov + v_xor: 2 extra VALU per
+// product, ~13 % of this path's VALU time), so on the device the two instructions are written out:
+//     t = (a.y*b.y, a.x*b.y)               v_pk_mul_f32  op_sel:[1,1] op_sel_hi:[0,1]
+//     a = (a.x*b.x - t.x, a.y*b.x + t.y)   v_pk_fma_f32  op_sel_hi:[1,0,1] neg_lo:[0,0,1]
+// Plain VALU, register operands only: no memory counters or hazard padding involved (cdna_hip_programming.md 5.7).
+OFDM_HD void cmul3(cf& a0, cf b0, cf& a1, cf b1, cf& a2, cf b2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    cf t0, t1, t2;
+    asm("v_pk_mul_f32 %3, %0, %6 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %4, %1, %7 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %2, %8 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %0, %6, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %7, %4 op_sel_hi:[1,0,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %2, %2, %8, %5 op_sel_hi:[1,0,1] neg_lo:[0,0,1]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : "v"(b0), "v"(b1), "v"(b2));
+#else
+    a0 = cmul(a0, b0);
+    a1 = cmul(a1, b1);
+    a2 = cmul(a2, b2);
+#endif
+}
+
 // cos/sin(2*pi*j/16), j = 0..7
 constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
                              0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
@@ -53,17 +77,17 @@ OFDM_HD cf mul_w(cf d) {
     if constexpr (J == 0) {
         return d;
     } else if constexpr (4 * J == R) {
-        return cf{d.y, -d.x};                                   // * -j
+        return d.yx * cf{1.f, -1.f};                            // * -j = (y, -x)
     } else if constexpr (8 * J == R) {
-        constexpr float c = 0.70710678118654752f;               // * (1-j)/sqrt2 : (x+y, y-x)*c
-        return (d + cf{d.y, -d.x}) * c;
+        constexpr float c = 0.70710678118654752f;               // * (1-j)/sqrt2 = (x+y, y-x)*c
+        return pk_fma(d.yx, cf{c, -c}, d * c);
     } else if constexpr (8 * J == 3 * R) {
-        constexpr float c = 0.70710678118654752f;               // * (-1-j)/sqrt2 : (y-x, -x-y)*c
-        return (cf{d.y, -d.x} - d) * c;
+        constexpr float c = 0.70710678118654752f;               // * (-1-j)/sqrt2 = (y-x, -x-y)*c
+        return pk_fma(d.yx, cf{c, -c}, d * (-c));
     } else {
-        constexpr float c = kCos16[J * (16 / R)];               // * (c - j s) : d*c + (y,-x)*s
+        constexpr float c = kCos16[J * (16 / R)];               // * (c - j s) = d*c + (y,-x)*s
         constexpr float s = kSin16[J * (16 / R)];
-        return pk_fma(cf{d.y, -d.x}, cf{s, s}, d * c);
+        return pk_fma(d.yx, cf{s, -s}, d * c);
     }
 }
 
@@ -148,11 +172,18 @@ OFDM_HD void fft_pass0_store(cf (&v)[Plan<N>::P], cf* lds, const LaneTwiddles<N>
     using PL = Plan<N>;
     dft_dif<PL::R0, 0, 1, PL::P>(v);
     constexpr int row = PL::THREE ? (PL::T + 2) : (PL::RL + 1);
+    constexpr int R = PL::R0;
+    if constexpr (R == 16) {
 #pragma unroll
-    for (int k0 = 0; k0 < PL::R0; ++k0) {
-        const cf val = v[bitrev(k0, PL::R0)];
-        lds[k0 * row + t] = (k0 == 0) ? val : cmul(val, tw.w0[k0]);
+        for (int k0 = 1; k0 < 16; k0 += 3)
+            cmul3(v[bitrev(k0, R)], tw.w0[k0], v[bitrev(k0 + 1, R)], tw.w0[k0 + 1], v[bitrev(k0 + 2, R)], tw.w0[k0 + 2]);
+    } else {   // R == 8: k0 = 1..7 -> 3 + 3 + 1
+        cmul3(v[bitrev(1, R)], tw.w0[1], v[bitrev(2, R)], tw.w0[2], v[bitrev(3, R)], tw.w0[3]);
+        cmul3(v[bitrev(4, R)], tw.w0[4], v[bitrev(5, R)], tw.w0[5], v[bitrev(6, R)], tw.w0[6]);
+        v[bitrev(7, R)] = cmul(v[bitrev(7, R)], tw.w0[7]);
     }
+#pragma unroll
+    for (int k0 = 0; k0 < R; ++k0) lds[k0 * row + t] = v[bitrev(k0, R)];
 }
 
 // pass 1 (3-pass plans): lane t' = n2*16 + k0
@@ -170,10 +201,11 @@ OFDM_HD void fft_pass1_store(cf (&v)[Plan<N>::P], cf* lds, const cf* w1tab, int 
     const int n2 = t >> 4, k0 = t & 15;
     dft_dif<16, 0, 1, PL::P>(v);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        const cf val = v[bitrev(k1, 16)];
-        lds[(k1 * 16 + k0) * (PL::RL + 1) + n2] = (k1 == 0) ? val : cmul(val, w1tab[n2 * 16 + k1]);
-    }
+    for (int k1 = 1; k1 < 16; k1 += 3)
+        cmul3(v[bitrev(k1, 16)], w1tab[n2 * 16 + k1], v[bitrev(k1 + 1, 16)], w1tab[n2 * 16 + k1 + 1], v[bitrev(k1 + 2, 16)],
+              w1tab[n2 * 16 + k1 + 2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) lds[(k1 * 16 + k0) * (PL::RL + 1) + n2] = v[bitrev(k1, 16)];
 }
 
 // last pass: loads, transforms; afterwards bin k = (t + T*j) + NC*kl sits in v[j*RL + bitrev(kl,RL)].

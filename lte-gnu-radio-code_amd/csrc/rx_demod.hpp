@@ -232,10 +232,10 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                     const float4 g01 = *reinterpret_cast<const float4*>(gsrc + idx);
                     const float4 g23 = (GLDS || four) ? *reinterpret_cast<const float4*>(gsrc + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
                     cf z[4];                                             // :235-248  x * p_est0 * e^{j..} * gain
-                    z[0] = cmul(cscale(x[q][0], scale), cf{g01.x, g01.y});
-                    z[1] = cmul(cscale(x[q][1], scale), cf{g01.z, g01.w});
-                    z[2] = cmul(cscale(x[q][2], scale), cf{g23.x, g23.y});
-                    z[3] = cmul(cscale(x[q][3], scale), cf{g23.z, g23.w});
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = cscale(x[q][e], scale);
+                    cmul3(z[0], cf{g01.x, g01.y}, z[1], cf{g01.z, g01.w}, z[2], cf{g23.x, g23.y});
+                    z[3] = cmul(z[3], cf{g23.z, g23.w});
                     if (a.eq) {
                         float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx);
                         const float4 o0 = float4{z[0].x, z[0].y, z[1].x, z[1].y}, o1 = float4{z[2].x, z[2].y, z[3].x, z[3].y};

@@ -24,7 +24,7 @@ d_bits = torch.empty((n_frames, nds * Kd * bps // 8), dtype=torch.uint8, device=
 st = torch.cuda.current_stream().cuda_stream
 res = {v: [] for v in variants}
 ref = None
-for rnd in range(6):
+for rnd in range(10):
     for v in variants:
         rxe.set_variant(v)
         rxe.demod_frames(d_rx, n_frames, fl, fl, d_eq, d_bits, om.BITS_PACKED, None, st)
