@@ -102,8 +102,11 @@ struct ofdm_rx {
     cf* f_htime = nullptr;
     int max_trials = 0;
     int variant = 0;
+    unsigned* d_stamps = nullptr;
     bool profiling = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static constexpr int PROF_RING = 32;       // per-call event triples: no host sync inside a timed loop
+    hipEvent_t ev[3 * PROF_RING] = {};
+    int64_t prof_calls = 0;
 };
 
 struct ofdm_tx {
@@ -168,21 +171,39 @@ int ofdm_rx_set_profiling(ofdm_rx* h, int32_t enable) {
     if (enable && !h->ev[0])
         for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
     h->profiling = enable != 0;
+    h->prof_calls = 0;
     return OFDM_OK;
 }
 
 int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms) {
-    if (!h || !h->ev[0]) return fail(OFDM_ERR_INVALID, "profiling was not enabled");
+    if (!h || !h->ev[0] || h->prof_calls == 0) return fail(OFDM_ERR_INVALID, "profiling was not enabled / no call recorded");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    HIP_TRY(hipEventSynchronize(h->ev[2]));
-    if (sync_ms) HIP_TRY(hipEventElapsedTime(sync_ms, h->ev[0], h->ev[1]));
-    if (demod_ms) HIP_TRY(hipEventElapsedTime(demod_ms, h->ev[1], h->ev[2]));
+    // mean over the calls recorded since ofdm_rx_set_profiling (at most the last PROF_RING of them)
+    const int64_t n = h->prof_calls < ofdm_rx::PROF_RING ? h->prof_calls : ofdm_rx::PROF_RING;
+    double ssum = 0, dsum = 0;
+    for (int64_t c = h->prof_calls - n; c < h->prof_calls; ++c) {
+        hipEvent_t* e = h->ev + 3 * (c % ofdm_rx::PROF_RING);
+        HIP_TRY(hipEventSynchronize(e[2]));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
+        ssum += a;
+        dsum += b;
+    }
+    if (sync_ms) *sync_ms = float(ssum / double(n));
+    if (demod_ms) *demod_ms = float(dsum / double(n));
     return OFDM_OK;
 }
 
 int ofdm_rx_set_variant(ofdm_rx* h, int32_t variant) {
     if (!h || variant < 0) return fail(OFDM_ERR_INVALID, "bad argument");
     h->variant = variant;
+    return OFDM_OK;
+}
+
+int ofdm_rx_set_stamp_buffer(ofdm_rx* h, void* d_stamps) {
+    if (!h) return fail(OFDM_ERR_INVALID, "null handle");
+    h->d_stamps = static_cast<unsigned*>(d_stamps);
     return OFDM_OK;
 }
 
@@ -351,9 +372,10 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
     sa.H_for_gain = nullptr;
     sa.gain = h->f_gain;
     sa.htime = h->f_htime;
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev[0], s));
+    hipEvent_t* pev = h->ev + 3 * (h->prof_calls % ofdm_rx::PROF_RING);
+    if (h->profiling) HIP_TRY(hipEventRecord(pev[0], s));
     HIP_TRY(launch_rx_sync(d, sa, s));
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev[1], s));
+    if (h->profiling) HIP_TRY(hipEventRecord(pev[1], s));
 
     if (n_dsym > 0 && (d_eq || d_bits)) {
         DemodArgs da{};
@@ -374,9 +396,13 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
         da.rows_per_frame = int(n_dsym);
         da.zero_skipped = 1;
         da.variant = h->variant;
+        da.stamps = h->d_stamps;
         HIP_TRY(launch_rx_demod(d, da, s));
     }
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev[2], s));
+    if (h->profiling) {
+        HIP_TRY(hipEventRecord(pev[2], s));
+        h->prof_calls += 1;
+    }
     if (d_tsr) HIP_TRY(hipMemcpyAsync(d_tsr, h->f_tsr, size_t(n_frames) * 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return n_dsym;
 }

@@ -25,6 +25,7 @@ struct DemodArgs {
     int rows_per_frame;
     int zero_skipped;        // write zeros for patterns whose guard fails (batch mode)
     int variant;             // kernel tuning variant (0 = default)
+    unsigned* stamps;        // diagnostic variant 9: [workgroups][waves][8] phase cycle sums, or null
 };
 
 // ---- RX sync search + LS estimate (reference: SynchAndChanEst.py:143-219, "Loop A") -----------

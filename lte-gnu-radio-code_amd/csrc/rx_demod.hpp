@@ -51,12 +51,94 @@ __device__ __forceinline__ unsigned hard_bits_rt(cf z, int mod) {
     return mod == 2 ? hard_bits<2>(z) : mod == 1 ? hard_bits<1>(z) : mod == 4 ? hard_bits<4>(z) : hard_bits<6>(z);
 }
 
+// Hard bits of 4 consecutive symbols, MSB-first, as one integer (4*MOD bits): the packed de-mapper's inner loop.
+// Each decision is a v_cmp into its own SGPR pair and one v_addc_co_u32 that shifts the bit into the word
+// (w = 2w + carry): 2 VALU per bit instead of cmp + cndmask + shift + or, and no s_nop between a compare and its
+// consumer (gfx950 needs wait states between a VALU writing an SGPR mask and a VALU reading it, so compares are
+// issued four to six at a time).  Same float compares as hard_bits<MOD>: results are bit-identical.
+template <int MOD, bool ASMB = true>
+__device__ __forceinline__ unsigned pack4(const cf (&z)[4]) {
+    unsigned w = 0;
+    if constexpr (!ASMB) {
+        w = (((((hard_bits<MOD>(z[0]) << MOD) | hard_bits<MOD>(z[1])) << MOD) | hard_bits<MOD>(z[2])) << MOD) | hard_bits<MOD>(z[3]);
+    } else if constexpr (MOD == 4) {
+        constexpr float t = 0.63245553203367588f;   // 2/sqrt(10)
+        unsigned long long m0, m1, m2, m3;
+#define OFDM_Q16(RE, IM)                                   \
+    "v_cmp_gt_f32_e64 %1, 0, " RE "\n\t"                   \
+    "v_cmp_gt_f32_e64 %2, 0, " IM "\n\t"                   \
+    "v_cmp_gt_f32_e64 %3, |" RE "|, %13\n\t"               \
+    "v_cmp_gt_f32_e64 %4, |" IM "|, %13\n\t"               \
+    "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"             \
+    "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"             \
+    "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"             \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+        asm(OFDM_Q16("%5", "%6") OFDM_Q16("%7", "%8") OFDM_Q16("%9", "%10") OFDM_Q16("%11", "%12")
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+            : "v"(z[0].x), "v"(z[0].y), "v"(z[1].x), "v"(z[1].y), "v"(z[2].x), "v"(z[2].y), "v"(z[3].x), "v"(z[3].y), "s"(t));
+#undef OFDM_Q16
+    } else if constexpr (MOD == 6) {
+        constexpr float a = 0.61721339984836765f;    // 4/sqrt(42)
+        constexpr float c = 0.30860669992418382f;    // 2/sqrt(42)
+        unsigned long long m0, m1, m2, m3, m4, m5;
+        float tr, ti;
+#define OFDM_Q64(RE, IM)                                   \
+    "v_sub_f32_e64 %7, |" RE "|, %17\n\t"                  \
+    "v_sub_f32_e64 %8, |" IM "|, %17\n\t"                  \
+    "v_cmp_gt_f32_e64 %1, 0, " RE "\n\t"                   \
+    "v_cmp_gt_f32_e64 %2, 0, " IM "\n\t"                   \
+    "v_cmp_gt_f32_e64 %3, |" RE "|, %17\n\t"               \
+    "v_cmp_gt_f32_e64 %4, |" IM "|, %17\n\t"               \
+    "v_cmp_gt_f32_e64 %5, |%7|, %18\n\t"                   \
+    "v_cmp_gt_f32_e64 %6, |%8|, %18\n\t"                   \
+    "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"             \
+    "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"             \
+    "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"             \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"             \
+    "v_addc_co_u32_e64 %0, %5, %0, %0, %5\n\t"             \
+    "v_addc_co_u32_e64 %0, %6, %0, %0, %6\n\t"
+        asm(OFDM_Q64("%9", "%10") OFDM_Q64("%11", "%12") OFDM_Q64("%13", "%14") OFDM_Q64("%15", "%16")
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&v"(tr), "=&v"(ti)
+            : "v"(z[0].x), "v"(z[0].y), "v"(z[1].x), "v"(z[1].y), "v"(z[2].x), "v"(z[2].y), "v"(z[3].x), "v"(z[3].y), "s"(a), "s"(c));
+#undef OFDM_Q64
+    } else if constexpr (MOD == 2) {
+        constexpr float t = 1.41421354f;             // largest float32 below sqrt(2): BitRecovery's outlier edge
+        unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+        // two symbols per group: bit = (x < 0) xor (|x| > sqrt2)
+#define OFDM_QPSK2(RE0, IM0, RE1, IM1)                     \
+    "v_cmp_gt_f32_e64 %1, 0, " RE0 "\n\t"                  \
+    "v_cmp_gt_f32_e64 %2, |" RE0 "|, %17\n\t"              \
+    "v_cmp_gt_f32_e64 %3, 0, " IM0 "\n\t"                  \
+    "v_cmp_gt_f32_e64 %4, |" IM0 "|, %17\n\t"              \
+    "v_cmp_gt_f32_e64 %5, 0, " RE1 "\n\t"                  \
+    "v_cmp_gt_f32_e64 %6, |" RE1 "|, %17\n\t"              \
+    "v_cmp_gt_f32_e64 %7, 0, " IM1 "\n\t"                  \
+    "v_cmp_gt_f32_e64 %8, |" IM1 "|, %17\n\t"              \
+    "s_xor_b64 %1, %1, %2\n\t"                             \
+    "s_xor_b64 %3, %3, %4\n\t"                             \
+    "s_xor_b64 %5, %5, %6\n\t"                             \
+    "s_xor_b64 %7, %7, %8\n\t"                             \
+    "s_nop 1\n\t"                                          \
+    "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"             \
+    "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"             \
+    "v_addc_co_u32_e64 %0, %5, %0, %0, %5\n\t"             \
+    "v_addc_co_u32_e64 %0, %7, %0, %0, %7\n\t"
+        asm(OFDM_QPSK2("%9", "%10", "%11", "%12") OFDM_QPSK2("%13", "%14", "%15", "%16")
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+            : "v"(z[0].x), "v"(z[0].y), "v"(z[1].x), "v"(z[1].y), "v"(z[2].x), "v"(z[2].y), "v"(z[3].x), "v"(z[3].y), "s"(t)
+            : "scc");
+#undef OFDM_QPSK2
+    } else {
+        w = (((((hard_bits<MOD>(z[0]) << MOD) | hard_bits<MOD>(z[1])) << MOD) | hard_bits<MOD>(z[2])) << MOD) | hard_bits<MOD>(z[3]);
+    }
+    return w;
+}
+
 // writes the bits of 4 (or `cnt`) consecutive list entries starting at list index idx of output row `orow`
-template <int MOD, int BMODE>
+template <int MOD, int BMODE, bool ASMB = true>
 __device__ __forceinline__ void store_bits(uint8_t* bits, int64_t sym0, const cf (&z)[4], int cnt) {
     if constexpr (BMODE == 1) {            // packed MSB-first: 4 symbols -> MOD/2 bytes (host guarantees Kd % 4 == 0, MOD even)
-        const unsigned w = (((((hard_bits<MOD>(z[0]) << MOD) | hard_bits<MOD>(z[1])) << MOD) | hard_bits<MOD>(z[2])) << MOD) |
-                           hard_bits<MOD>(z[3]);
+        const unsigned w = pack4<MOD, ASMB>(z);
         uint8_t* o = bits + sym0 * MOD / 8;
         if constexpr (MOD == 2) {
             o[0] = uint8_t(w);
@@ -96,7 +178,7 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
@@ -138,6 +220,18 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     }
 
     const int n_iter = (a.spc + NS - 1) / NS;
+    // STAMP (diagnostic build only, never timed): cycles per phase, summed over the chunk, one row per wave
+    unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            unsigned long long tn;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn)::"memory");
+            acc[i] += unsigned(tn - tprev);
+            tprev = tn;
+        }
+    };
+    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
     for (int it = 0; it < n_iter; ++it) {
         const int ds = ds0 + it * NS + slot;
         const bool sym_valid = active && ds < ds1;
@@ -163,7 +257,25 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
             }
         }
-        wg_fft<N>(v, lds, tw, w1tab, t);                                 // :230
+        stamp(0);                                                        // loop top .. loads issued
+        if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(1);                                                        // .. loads landed
+        if constexpr (STAMP) {
+            fft_pass0_store<N>(v, lds, tw, t);
+            wg_barrier();
+            stamp(2);                                                    // .. pass 0 + exchange A written
+            if constexpr (PL::THREE) {
+                fft_pass1_load<N>(v, lds, t);
+                wg_barrier();
+                fft_pass1_store<N>(v, lds, w1tab, t);
+                wg_barrier();
+            }
+            stamp(3);                                                    // .. pass 1 + exchange B written
+            fft_last_load<N>(v, lds, t);
+            fft_last_dft<N>(v);
+        } else {
+            wg_fft<N>(v, lds, tw, w1tab, t);                             // :230
+        }
         wg_barrier();                                                    // exchange region -> staging region
 
         // Re-materialise Kd per symbol so hipcc does not hoist 16 per-slot list offsets into VGPRs held across the loop.
@@ -193,6 +305,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         }
         wg_barrier();
 
+        stamp(4);                                                        // .. pass 2 + scatter into list order
         // each lane owns 4 consecutive list entries per q: 16 B LDS reads, 16 B global stores
         cf x[Q][4];
         float psum = 0.f;
@@ -222,6 +335,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
             for (int w = 0; w < T / 64; ++w) psum += red[w];
         }
         const float scale = sqrtf(float(Kd_) / psum);                    // :233 p_est0
+        stamp(5);                                                        // .. list read + power sum
 
         if (compute) {
 #pragma unroll
@@ -249,7 +363,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                             if (four) o[1] = o1;
                         }
                     }
-                    if constexpr (BMODE != 0) store_bits<MOD, BMODE>(a.bits, orow * Kd_ + idx, z, four ? 4 : 2);
+                    if constexpr (BMODE != 0) store_bits<MOD, BMODE, ASMB>(a.bits, orow * Kd_ + idx, z, four ? 4 : 2);
                 }
             }
         } else if (sym_valid && a.zero_skipped) {                        // pattern guard failed: defined (zero) output
@@ -268,7 +382,16 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 }
             }
         }
+        stamp(6);                                                        // .. equalise + de-map + stores issued
         wg_barrier();                                                    // staging region free for the next symbol
+        stamp(7);                                                        // .. loop-end barrier
+    }
+    if constexpr (STAMP) {
+        if ((tid & 63) == 0 && a.stamps) {
+            unsigned* o = a.stamps + (int64_t(blockIdx.x) * (DG::WG / 64) + (tid >> 6)) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = acc[i];
+        }
     }
 }
 
@@ -295,6 +418,8 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         if (a.variant != 0 && a.variant < 100 && bmode == 1 && a.mod == 4) {
             if (a.variant == 1) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 2) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, true>), dim3(grid), dim3(DG::WG), DG::lds_bytes(rx.Kd, false), s, rx, a);
+            if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             return hipGetLastError();
         }
     }
