@@ -180,7 +180,6 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
         o[2] = found ? int(ms) : 0;                                                      // :175
         o[3] = found ? 1 : 0;
     }
-    cf Hreg[P];
 #pragma unroll
     for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
@@ -200,7 +199,7 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
             cf Hk = cf{0.f, 0.f};
             if (found && neg) Hk = Hn;
             if (found && pos) Hk = Hp;
-            Hreg[s] = Hk;
+            if (a.htime) lds[k] = Hk;              // natural-order copy for the est_chan_time inverse FFT below
             if (active) {
                 a.H[int64_t(frame) * N + k] = Hk;
                 if (a.eqg || a.esf) {
@@ -232,11 +231,6 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
         }
     }
     if (a.htime) {                                                                      // :202,212  ifft(chan_est1)
-#pragma unroll
-        for (int j = 0; j < PL::C; ++j) {
-#pragma unroll
-            for (int kl = 0; kl < PL::RL; ++kl) lds[(t + T * j) + PL::NC * kl] = Hreg[out_slot<N>(j, kl)];
-        }
         wg_barrier();
         cf v[P];
 #pragma unroll
