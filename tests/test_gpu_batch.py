@@ -213,3 +213,26 @@ def test_loopback_property_full_size_numerology(om):
     d_rx.upload((x * np.complex64(3.0)).astype(np.complex64))
     rxe.demod_frames(d_rx, n_frames, fl, fl, d_eq, None, om.BITS_NONE, None)
     assert relerr(d_eq.download(np.complex64, n_frames * nds * Kd), eq1) < TOL
+
+
+def test_offline_modulator_mirror_reproduces_fixture(om, golden):
+    """The reference's SDRScript flow through the mirrored classes: bits fixture -> tx_data_online / tx_data_offline."""
+    from ofdm_mi355x.txrx_mod import OFDM, MultiAntennaSystem, SynchSignal
+    fx = golden("ref_fixtures.npz")
+    N, cp, Kd, n_sym = 64, 16, 60, 240
+    all_bins = np.array(list(range(-Kd // 2, 0)) + list(range(1, Kd // 2 + 1)))
+    pat = np.tile(np.array([0, 1, 1, 1]), n_sym // 4)
+    mas = MultiAntennaSystem(OFDM(cp, Kd, "QPSK", N, 15e3), 1, "SpMult", all_bins, n_sym, pat, 15e3 * N, "LTE-TU", 0, "Fading",
+                             1, all_bins, np.array([], dtype=int))
+    caz = SynchSignal(cp, N - 2, 1, N, np.array([1, 3]))
+    assert relerr(caz.ZChu0, orc.zadoff_chu(62, 23)) < 1e-12
+    mas.multi_ant_binary_map(caz, fx["tx_bits"], np.array([1, 3]))
+    mas.multi_ant_symb_gen(n_sym)
+    assert relerr(mas.buffer_data_tx_time[0], fx["tx_online"][0]) < TOL
+    mas.rx_signal_gen()
+    assert mas.buffer_data_rx_time.shape == fx["tx_offline"].shape
+    assert np.max(np.abs(mas.buffer_data_rx_time[0] - fx["tx_offline"][0])) < 2e-4       # fixture carries 100 dB AWGN
+    mas.additive_noise("Digital", 20, "Fading", "Complex")
+    noise = mas.buffer_data_rx_time[0] - orc.channel_apply(mas.buffer_data_tx_time[0], orc.REF_TAPS, N)
+    nz = noise[:mas._noise_len]
+    assert abs(np.var(nz) / mas.noise_var - 1) < 0.1 and not noise[mas._noise_len:].any()
