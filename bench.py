@@ -245,11 +245,34 @@ def main():
                     traffic = json.load(open(tf)).get(args.config)
                 except Exception:
                     traffic = None
+            # same-run context: this chip's float4 device-copy rate and the demod access pattern without arithmetic
+            from ofdm_mi355x import _lib as ol
+            def _probe(mode):
+                ts = []
+                nb = d_eq.numel() * 4 if d_eq is not None else d_bits.numel()
+                nb -= nb % 16
+                dst = d_eq if d_eq is not None else d_bits
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ol.check(rxe.lib.ofdm_bandwidth_probe(device, ol.ptr(d_rx), ol.ptr(dst), nb, mode, N * 8, cp * 8, (Kd * 8) & ~15, dsym if d_eq is not None else 0, stream))
+                    e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return float(np.median(ts)), nb
+            cms, cnb = _probe(0)
+            copy_gbs = 2 * cnb / cms / 1e6
+            pat_gbs = None
+            if d_eq is not None:
+                pms, _ = _probe(1)
+                pat_gbs = dsym * (L * 8 + Kd * 8) / pms / 1e6
             roof = dict(bound="hbm", kernel="rx_demod_kernel<%d>" % N, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                         algorithmic_bytes_per_launch=int(alg), kernel_ms=round(dm, 4),
                         sync_kernel_ms=round(float(np.mean(k_sync)), 4),
-                        read_only_frac=round(dsym * L * 8 / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                        read_only_frac=round(dsym * L * 8 / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        measured_copy_GBs=round(copy_gbs, 1),
+                        access_pattern_no_math_GBs=None if pat_gbs is None else round(pat_gbs, 1))
         cpu = None
         if world == 1 and not args.no_cpu:
             iq_host = d_rx[:16].cpu().numpy().view(np.complex64).reshape(16, fl)

@@ -173,6 +173,11 @@ int ofdm_channel_apply(ofdm_tx* h, const float* d_in, int64_t n_frames, int64_t 
                        uint64_t seed, float* d_out, int64_t out_stride, int64_t out_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------ misc */
+/* Measurement aid for bench.py: mode 0 = float4 device copy of `bytes` (achievable HBM rate of this chip, same run);
+ * mode 1 = the demod kernel's access pattern without arithmetic (per symbol: skip gap_bytes, read sym_in_bytes, write
+ * sym_out_bytes).  Asynchronous on `stream`. */
+int ofdm_bandwidth_probe(int32_t device, const void* d_in, void* d_out, int64_t bytes, int32_t mode, int32_t sym_in_bytes,
+                         int32_t gap_bytes, int32_t sym_out_bytes, int64_t n_sym, void* stream);
 int ofdm_abi_version(void);
 const char* ofdm_last_error(void);
 /* plain device memory helpers so hosts without torch can drive the batch path */

@@ -631,6 +631,16 @@ int ofdm_demap(ofdm_rx* h, const float* d_sym, int64_t n, int32_t modulation, ui
     return OFDM_OK;
 }
 
+int ofdm_bandwidth_probe(int32_t device, const void* d_in, void* d_out, int64_t bytes, int32_t mode, int32_t sym_in_bytes,
+                         int32_t gap_bytes, int32_t sym_out_bytes, int64_t n_sym, void* stream) {
+    if (!d_in || !d_out || bytes < 0 || (bytes & 15) || (sym_in_bytes & 15) || (gap_bytes & 15) || (sym_out_bytes & 15))
+        return fail(OFDM_ERR_INVALID, "ofdm_bandwidth_probe: sizes must be multiples of 16 bytes");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(launch_probe(d_in, d_out, bytes / 16, mode, sym_in_bytes / 16, gap_bytes / 16, sym_out_bytes / 16, n_sym,
+                         static_cast<hipStream_t>(stream)));
+    return OFDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------ TX
 int ofdm_tx_destroy(ofdm_tx* h) {
     if (!h) return OFDM_OK;

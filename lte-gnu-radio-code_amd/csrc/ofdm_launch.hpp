@@ -95,5 +95,7 @@ hipError_t launch_demap(const DemapArgs& a, hipStream_t s);
 hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s);
 hipError_t launch_channel(const ChanArgs& a, hipStream_t s);
 size_t rx_lds_bytes(int nfft);
+hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
+                        hipStream_t s);
 
 }  // namespace ofdm

@@ -184,6 +184,35 @@ __global__ void __launch_bounds__(256) channel_kernel(ChanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ bandwidth probes
+// mode 0: float4 copy (the chip's achievable HBM rate for bench.py's roofline context)
+// mode 1: the demod kernel's access pattern with no arithmetic: per symbol read N*8 B (skipping cp*8 B), write Kd*8 B
+__global__ void __launch_bounds__(256) probe_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n16, int mode,
+                                                     int sym_in16, int gap16, int sym_out16, int64_t n_sym) {
+    if (mode == 0) {
+        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += int64_t(gridDim.x) * blockDim.x) out[i] = in[i];
+    } else {
+        for (int64_t s = blockIdx.x; s < n_sym; s += gridDim.x) {
+            const float4* src = in + s * (sym_in16 + gap16) + gap16;
+            float4* dst = out + s * sym_out16;
+            float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+            for (int i = threadIdx.x; i < sym_in16; i += blockDim.x) {
+                const float4 v = src[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            for (int i = threadIdx.x; i < sym_out16; i += blockDim.x) dst[i] = acc;
+        }
+    }
+}
+
+hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
+                        hipStream_t s) {
+    const unsigned grid = mode == 0 ? 256 * 16 : unsigned(std::min<int64_t>(n_sym, 256 * 32));
+    hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), 0, s, static_cast<const float4*>(in), static_cast<float4*>(out), n16, mode,
+                       sym_in16, gap16, sym_out16, n_sym);
+    return hipGetLastError();
+}
+
 template <int N>
 static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s) {
     const int64_t units = int64_t(a.n_frames) * a.n_sym;

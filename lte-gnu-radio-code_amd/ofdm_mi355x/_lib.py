@@ -59,6 +59,8 @@ PROTOTYPES = {
     "ofdm_memcpy_h2d": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "ofdm_memcpy_d2h": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "ofdm_device_synchronize": (C.c_int, [C.c_int32]),
+    "ofdm_bandwidth_probe": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int64, C.c_void_p]),
     "ofdm_rx_create": (C.c_int, [C.POINTER(RxCfg), C.POINTER(C.c_void_p)]),
     "ofdm_rx_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_rx_work": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(RxReport)]),

@@ -32,21 +32,31 @@ def main():
     frame_len = iq.shape[1]
     n_sym_i = 16 if N >= 1024 else min(240, frame_len // L)
     sample = iq[0][: n_sym_i * L]
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        rx = orc.RxOracle(n_sym_i, N, cp, N - 2, [1, 3], Kd, snr, 0.7)
-        orc.rx_work_faithful_ops(rx, sample)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or reps >= 200:
-            break
-    faithful = reps * len(sample) / dt / 1e6
+    # BLAS decides how many threads the dense diag products use; try a modest and the full pool, keep the faster
     try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_info, threadpool_limits
+        max_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
-        blas_threads = os.cpu_count() or 1
+        threadpool_limits = None
+        max_threads = os.cpu_count() or 1
+    best = None
+    for nthr in sorted({min(8, max_threads), max_threads}):
+        ctx = threadpool_limits(limits=nthr) if threadpool_limits else None
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            rx = orc.RxOracle(n_sym_i, N, cp, N - 2, [1, 3], Kd, snr, 0.7)
+            orc.rx_work_faithful_ops(rx, sample)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2 or reps >= 200:
+                break
+        if ctx is not None:
+            ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
+        rate = reps * len(sample) / dt / 1e6
+        if best is None or rate > best[0]:
+            best = (rate, nthr, reps, dt)
+    faithful, blas_threads, reps, dt = best
     cores = min(os.cpu_count() or 1, 16, len(iq))
     ocfg = dict(nfft=N, cp_len=cp, synch_dat=(1, 3), num_synch_bins=N - 2, num_data_bins=Kd, snr=snr)
     per = max(1, len(iq) // cores)
