@@ -178,7 +178,7 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
@@ -232,31 +232,53 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         }
     };
     if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-    for (int it = 0; it < n_iter; ++it) {
+    // Per-symbol bookkeeping (uniform per slot).  SynchAndChanEst.py:222-223: data_ptr = tsr0 + S*L*(P+1), P = p*(S+D),
+    // guarded once per pattern; :226: CP strip by offset.
+    struct Sym {
+        bool valid, compute;
+        int64_t start, orow;
+    };
+    auto sym_of = [&](int it) {
+        Sym sy;
         const int ds = ds0 + it * NS + slot;
-        const bool sym_valid = active && ds < ds1;
+        sy.valid = active && it < n_iter && ds < ds1;
         const int p = ds / D, n_ = ds - p * D;
-        // SynchAndChanEst.py:222-223  data_ptr = tsr0 + S*L*(P+1), P = p*(S+D); guard once per pattern
         const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
-        const bool compute = sym_valid && (pat_ptr + N - 1 <= a.frame_len);
-        const int64_t start = pat_ptr + int64_t(L) * n_;                 // :226 CP strip by offset
-        const int64_t orow = int64_t(frame) * a.rows_per_frame + (p * a.row_stride_pat + n_);
-
-        cf v[P];
-        if (compute && start + N <= a.frame_len) {
-            const cf* src = frame_iq + start + t;
+        sy.compute = sy.valid && (pat_ptr + N - 1 <= a.frame_len);
+        sy.start = pat_ptr + int64_t(L) * n_;
+        sy.orow = int64_t(frame) * a.rows_per_frame + (p * a.row_stride_pat + n_);
+        return sy;
+    };
+    cf v[P];
+    auto load_sym = [&](const Sym& sy) {
+        if (sy.compute && sy.start + N <= a.frame_len) {
+            const cf* src = frame_iq + sy.start + t;
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) v[n0] = NT ? __builtin_nontemporal_load(src + T * n0) : src[T * n0];
         } else {                                                         // short tail: fft(x, N) zero-pads (:230)
             const int64_t last = a.frame_len > 0 ? a.frame_len - 1 : 0;
-            const bool any = compute && a.frame_len > 0;
+            const bool any = sy.compute && a.frame_len > 0;
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) {
-                const int64_t idx = start + t + T * n0;
+                const int64_t idx = sy.start + t + T * n0;
                 const cf x = any ? frame_iq[idx < last ? idx : last] : cf{0.f, 0.f};
                 v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
             }
         }
+    };
+
+    // Software pipeline: the data VGPRs are dead once a symbol's bins are scattered into LDS, so the NEXT symbol's
+    // loads are issued right there and are in flight during the power sum / equalise / store phases (~45 % of a
+    // symbol's time) -- the HBM latency (~25 % of a wave's time when exposed) is hidden at no register cost.
+    Sym cur = sym_of(0);
+    if constexpr (PIPE) load_sym(cur);
+    for (int it = 0; it < n_iter; ++it) {
+        if constexpr (!PIPE) {
+            cur = sym_of(it);
+            load_sym(cur);
+        }
+        const bool sym_valid = cur.valid, compute = cur.compute;
+        const int64_t orow = cur.orow;
         stamp(0);                                                        // loop top .. loads issued
         if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(1);                                                        // .. loads landed
@@ -306,24 +328,25 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         wg_barrier();
 
         stamp(4);                                                        // .. pass 2 + scatter into list order
-        // each lane owns 4 consecutive list entries per q: 16 B LDS reads, 16 B global stores
-        cf x[Q][4];
+        if constexpr (PIPE) {
+            cur = sym_of(it + 1);
+            load_sym(cur);                                               // next symbol: in flight until the next FFT
+        }
+        // each lane owns 4 consecutive list entries per q: 16 B LDS reads (read twice: power sum now, output below)
         float psum = 0.f;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int idx = 4 * (t + T * q);
             const float4 a01 = *reinterpret_cast<const float4*>(lds + idx);
             const float4 a23 = *reinterpret_cast<const float4*>(lds + idx + 2);
-            x[q][0] = cf{a01.x, a01.y};
-            x[q][1] = cf{a01.z, a01.w};
-            x[q][2] = cf{a23.x, a23.y};
-            x[q][3] = cf{a23.z, a23.w};
+            const float p4[4] = {a01.x * a01.x + a01.y * a01.y, a01.z * a01.z + a01.w * a01.w,
+                                 a23.x * a23.x + a23.y * a23.y, a23.z * a23.z + a23.w * a23.w};
             if (4 * T * (q + 1) <= Kd_) {                                // whole wavefront row inside the list (uniform)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) psum += cnorm2(x[q][e]);
+                for (int e = 0; e < 4; ++e) psum += p4[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) psum += (idx + e < Kd_) ? cnorm2(x[q][e]) : 0.f;
+                for (int e = 0; e < 4; ++e) psum += (idx + e < Kd_) ? p4[e] : 0.f;
             }
         }
         psum = lanes_sum<T>(psum);                                       // :233 sum |x|^2 over the Kd listed bins
@@ -345,9 +368,10 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                     const bool four = idx + 2 < Kd_;
                     const float4 g01 = *reinterpret_cast<const float4*>(gsrc + idx);
                     const float4 g23 = (GLDS || four) ? *reinterpret_cast<const float4*>(gsrc + idx + 2) : float4{0.f, 0.f, 0.f, 0.f};
-                    cf z[4];                                             // :235-248  x * p_est0 * e^{j..} * gain
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) z[e] = cscale(x[q][e], scale);
+                    const float4 a01 = *reinterpret_cast<const float4*>(lds + idx);
+                    const float4 a23 = *reinterpret_cast<const float4*>(lds + idx + 2);
+                    cf z[4] = {cf{a01.x, a01.y} * scale, cf{a01.z, a01.w} * scale, cf{a23.x, a23.y} * scale,
+                               cf{a23.z, a23.w} * scale};                 // :235-248  x * p_est0 * e^{j..} * gain
                     cmul3(z[0], cf{g01.x, g01.y}, z[1], cf{g01.z, g01.w}, z[2], cf{g23.x, g23.y});
                     z[3] = cmul(z[3], cf{g23.z, g23.w});
                     if (a.eq) {
@@ -419,6 +443,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             if (a.variant == 1) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 2) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, true>), dim3(grid), dim3(DG::WG), DG::lds_bytes(rx.Kd, false), s, rx, a);
             if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 5) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             return hipGetLastError();
         }
