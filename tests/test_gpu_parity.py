@@ -192,3 +192,60 @@ def test_tx_replay_blocks(om, tmp_path, golden):
         assert np.array_equal(out[:4000], arr[0].astype(np.complex64)) and not out[4000:].any()
         with pytest.raises(ValueError):
             blk.work([], [np.zeros(100, np.complex64)])        # buffer shorter than the stored IQ (numpy raises)
+
+
+def test_ofdm_chain_wiring_num_synch_bins_equals_nfft(om):
+    """`ofdm_chain.py:83` passes num_synch_bins = nfft = 64: bin N/2 is listed twice, DC never.  Same arithmetic as the
+    oracle (duplicates in the correlation and power sum, last-write-wins in est_chan_freq_P)."""
+    N, cp, Kd, n_sym = 64, 16, 60, 8
+    rng = np.random.default_rng(21)
+    bits = rng.integers(0, 2, 6 * Kd * 2)
+    tx = orc.tx_modulate(bits, N, cp, N, Kd, n_sym)                      # TX with the same 64-bin sync list
+    iq = np.concatenate([np.zeros(2), orc.channel_apply(tx, orc.REF_TAPS, N)[:n_sym * 80 + 16]]).astype(np.complex64)
+    o = orc.RxOracle(n_sym, N, cp, N, [1, 3], Kd, 100, 0.7, force_fp64=True)
+    o.work(iq, np.zeros(len(iq), np.complex64))
+    import utsa_ofdm
+    blk = utsa_ofdm.SynchAndChanEst(n_sym, N, cp, N, [1, 3], Kd, 100, 0.7, "/tmp/", "x", 0, 0)
+    blk.work([iq], [np.zeros(len(iq), np.complex64)])
+    assert o.time_synch_ref[2] > 0
+    _check_tsr(blk.time_synch_ref, o.time_synch_ref)
+    assert relerr(blk.est_chan_freq_P[0], o.est_chan_freq_P[0]) < TOL
+    assert relerr(blk.est_data_freq, o.est_data_freq) < TOL
+    assert relerr(blk.est_synch_freq[0], o.est_synch_freq[0]) < TOL
+    # data bins = nfft as well (every bin but DC, N/2 twice)
+    o2 = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], N, 100, 0.7, force_fp64=True)
+    tx2 = orc.tx_modulate(rng.integers(0, 2, 6 * N * 2), N, cp, N - 2, N, n_sym)
+    iq2 = tx2.astype(np.complex64)
+    o2.work(iq2, np.zeros(len(iq2), np.complex64))
+    blk2 = utsa_ofdm.SynchAndChanEst(n_sym, N, cp, N - 2, [1, 3], N, 100, 0.7, "/tmp/", "x", 0, 0)
+    blk2.work([iq2], [np.zeros(len(iq2), np.complex64)])
+    assert relerr(blk2.est_data_freq, o2.est_data_freq) < TOL
+
+
+def test_stream_block_call_sequence_state(om, golden):
+    """Five consecutive work() calls with different buffers on ONE instance: count/corr_obs gating, the distance rule,
+    the row-0 equaliser kept from the first detection, est_chan_freq_P[1] updated by later detections, emitted output."""
+    fx = golden("ref_fixtures.npz")
+    N, cp, Kd = 64, 16, 60
+    base = fx["tx_offline"][0].astype(np.complex64)
+    rng = np.random.default_rng(4)
+    bufs = []
+    for i in range(5):
+        lead = int(rng.integers(0, 9))
+        noise = (0.002 * (rng.standard_normal(lead) + 1j * rng.standard_normal(lead))).astype(np.complex64)
+        bufs.append(np.concatenate([noise, base * np.complex64(1.0 + 0.1 * i)])[:19200 + 63])
+    o = orc.RxOracle(240, N, cp, N - 2, [1, 3], Kd, 100, 0.7, force_fp64=True)
+    blk = _block(240, N, cp, Kd)
+    for i, b in enumerate(bufs):
+        oo = np.zeros(len(b), np.complex64)
+        bo = np.zeros(len(b), np.complex64)
+        o.work(b, oo)
+        blk.work([b], [bo])
+        _check_tsr(blk.time_synch_ref, o.time_synch_ref)
+        assert (blk.count, blk.corr_obs) == (o.count, o.corr_obs)
+        assert relerr(blk.est_data_freq, o.est_data_freq) < TOL, i
+        assert relerr(bo, oo) < TOL, i
+        assert relerr(blk.est_chan_freq_P[0], o.est_chan_freq_P[0]) < TOL
+        if i > 0:
+            assert relerr(blk.est_chan_freq_P[1], o.est_chan_freq_P[1]) < TOL
+            assert relerr(blk.est_chan_time[1], o.est_chan_time[1]) < TOL

@@ -1,0 +1,55 @@
+"""Randomised GPU parity (hypothesis): frame batches with random numerology, offsets, gains and channel taps vs the fp64 oracle."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from conftest import relerr
+from oracle import ofdm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@given(logn=st.integers(6, 11), kd_frac=st.floats(0.3, 0.95), cp_frac=st.floats(0.04, 0.24), n_pat=st.integers(1, 3),
+       n_frames=st.integers(1, 5), lead=st.integers(0, 7), gain=st.floats(0.05, 20.0), seed=st.integers(0, 2 ** 31 - 1),
+       mod=st.sampled_from(["QPSK", "16QAM", "64QAM"]))
+def test_batch_random_numerology(logn, kd_frac, cp_frac, n_pat, n_frames, lead, gain, seed, mod):
+    import ofdm_mi355x as om
+    N = 1 << logn
+    cp = max(8, int(N * cp_frac))
+    Kd = max(8, int((N - 2) * kd_frac) // 4 * 4)
+    n_sym = 4 * n_pat
+    L = N + cp
+    rng = np.random.default_rng(seed)
+    bps = orc.BITS_PER_SYMBOL[mod]
+    taps = (rng.standard_normal(3) + 1j * rng.standard_normal(3)) * np.array([1.0, 0.4, 0.15])
+    lead = min(lead, cp // 2)
+    frame_len = n_sym * L + lead + 3
+    iq = np.zeros((n_frames, frame_len), np.complex64)
+    bits = rng.integers(0, 2, (n_frames, n_pat * 3 * Kd * bps)).astype(np.uint8)
+    for f in range(n_frames):
+        tx = orc.tx_modulate(bits[f], N, cp, N - 2, Kd, n_sym, modulation=mod)
+        y = gain * orc.channel_apply(tx, taps, N)[:n_sym * L + 3]
+        iq[f, lead:] = y
+    rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.5, modulation=mod)
+    nds = rx.data_symbols_per_frame(frame_len)
+    d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+    d_eq = om.DeviceBuffer(max(8, n_frames * nds * Kd * 8))
+    d_bu = om.DeviceBuffer(max(8, n_frames * nds * Kd * bps))
+    d_tsr = om.DeviceBuffer(n_frames * 16)
+    assert rx.demod_frames(d_iq, n_frames, frame_len, frame_len, d_eq, d_bu, om.BITS_UNPACKED, d_tsr) == nds == 3 * n_pat
+    eq = d_eq.download(np.complex64, n_frames * nds * Kd).reshape(n_frames, nds, Kd)
+    bu = d_bu.download(np.uint8, n_frames * nds * Kd * bps).reshape(n_frames, -1)
+    tsr = d_tsr.download(np.int32, n_frames * 4).reshape(n_frames, 4)
+    rows = [r for r in range(n_sym) if r % 4 != 3]
+    for f in range(n_frames):
+        o = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 100, 0.5, force_fp64=True)
+        o.work(iq[f], np.zeros(frame_len, np.complex64))
+        # a detection that sits within fp32 rounding of the gate may legitimately differ: skip such frames
+        m = np.max(np.abs(o.del_mat)) if o.del_mat is not None else 0.0
+        if abs(m - 0.5 * o.MM) < 1e-3 * o.MM:
+            continue
+        assert tsr[f, 0] == o.time_synch_ref[0] and tsr[f, 1] == o.time_synch_ref[1]
+        assert relerr(eq[f], o.est_data_freq[rows]) < 2e-5
+        assert np.array_equal(bu[f], orc.demap_hard(eq[f].ravel(), mod))
