@@ -39,6 +39,10 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
             v[n0] = (active && idx < frame_len) ? frame_iq[idx] : cf{0.f, 0.f};
         }
         wg_fft<N>(v, lds, tw, w1tab, t);                                                       // :152
+        int Ks_ = rx.Ks;                      // opaque per segment: keeps the 32 per-slot table offsets out of long-lived VGPRs
+        asm volatile("" : "+s"(Ks_));
+        const cf* zcs = rx.zc + LL * Ks_;
+        cf* ys = yscratch ? yscratch + LL * Ks_ : nullptr;
 #pragma unroll
         for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
@@ -46,20 +50,20 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
                 const int k = (t + T * j) + PL::NC * kl;
                 const int s = out_slot<N>(j, kl);
                 int in_, ip_;
-                const bool neg = bin_neg(k, rx.Ks, N, in_);
-                const bool pos = bin_pos(k, rx.Ks, ip_);
+                const bool neg = bin_neg(k, Ks_, N, in_);
+                const bool pos = bin_pos(k, Ks_, ip_);
                 if (neg) {                                                              // :153-161
-                    const cf c = cmulc(v[s], rx.zc[LL * rx.Ks + in_]);
+                    const cf c = cmulc(v[s], zcs[in_]);
                     Z[s] = Z[s] + c;
                     psum += cnorm2(v[s]);
                     if (pos) zdup = zdup + c;
-                    if (yscratch && active) yscratch[LL * rx.Ks + in_] = v[s];
+                    if (ys && active) ys[in_] = v[s];
                 }
                 if (pos) {
-                    const cf c = cmulc(v[s], rx.zc[LL * rx.Ks + ip_]);
+                    const cf c = cmulc(v[s], zcs[ip_]);
                     Z[s] = Z[s] + c;
                     psum += cnorm2(v[s]);
-                    if (yscratch && active) yscratch[LL * rx.Ks + ip_] = v[s];
+                    if (ys && active) ys[ip_] = v[s];
                 }
             }
         }
@@ -143,32 +147,56 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
     cf* ysc = a.yscratch ? a.yscratch + int64_t(frame) * rx.MM : nullptr;
 
     bool found = false;
-    cf Zs[P];
+    cf Zs[P];                       // Z of the accepted trial
     cf zdups = cf{0.f, 0.f};
     float pests = 0.f, ms = 0.f;
     int dhats = 0, Phit = 0;
+    if constexpr (PL::SLOTS == 1) {
+        // one frame per workgroup: every decision is workgroup-uniform, so the accepted trial's registers are used
+        // in place (no second copy of Z to keep alive across the search loop)
+        for (int it = 0;; ++it) {
+            const int Ptrial = a.p_begin + it;
+            const bool valid = active && (a.p_count <= 0 || it < a.p_count) &&
+                               (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+            if (!valid) break;
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc);
+            if (a.force_accept || ms > rx.gate_mm) {                                    // :166
+                found = true;
+                Phit = Ptrial;
+                break;
+            }
+        }
+        if (!found) {
 #pragma unroll
-    for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
-
-    for (int it = 0;; ++it) {
-        const int Ptrial = a.p_begin + it;
-        const bool valid = active && !found && (a.p_count <= 0 || it < a.p_count) &&
-                           (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
-        if (!__syncthreads_or(valid ? 1 : 0)) break;
-        cf Z[P];
-        cf zdup;
-        float p_est, m;
-        int dhat;
-        sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc);
-        if (valid && (a.force_accept || m > rx.gate_mm)) {                              // :166
-            found = true;
+            for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
+            zdups = cf{0.f, 0.f};
+            pests = 0.f;
+            ms = 0.f;
+            dhats = 0;
+        }
+    } else {
 #pragma unroll
-            for (int s = 0; s < P; ++s) Zs[s] = Z[s];
-            zdups = zdup;
-            pests = p_est;
-            ms = m;
-            dhats = dhat;
-            Phit = Ptrial;
+        for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
+        for (int it = 0;; ++it) {
+            const int Ptrial = a.p_begin + it;
+            const bool valid = active && !found && (a.p_count <= 0 || it < a.p_count) &&
+                               (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+            if (!__syncthreads_or(valid ? 1 : 0)) break;
+            cf Z[P];
+            cf zdup;
+            float p_est, m;
+            int dhat;
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc);
+            if (valid && (a.force_accept || m > rx.gate_mm)) {                          // :166
+                found = true;
+#pragma unroll
+                for (int s = 0; s < P; ++s) Zs[s] = Z[s];
+                zdups = zdup;
+                pests = p_est;
+                ms = m;
+                dhats = dhat;
+                Phit = Ptrial;
+            }
         }
     }
 
@@ -180,54 +208,62 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
         o[2] = found ? int(ms) : 0;                                                      // :175
         o[3] = found ? 1 : 0;
     }
+    // Z (register slot order) -> LDS in natural bin order, then a rolled loop over this lane's bins: the finalize
+    // arithmetic runs once per frame, so it is kept small in registers rather than unrolled 16-fold.
 #pragma unroll
     for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
         for (int kl = 0; kl < PL::RL; ++kl) {
             const int k = (t + T * j) + PL::NC * kl;
-            const int s = out_slot<N>(j, kl);
-            int in_, ip_;
-            const bool neg = bin_neg(k, Ks, N, in_);
-            const bool pos = bin_pos(k, Ks, ip_);
-            const cf rot = cconj(rx.tw[(dhats * k) & (N - 1)]);                         // e^{+j 2pi d k/N}  :177
-            const float sc = pests * rx.inv_ls;                                         // p_est / (S (1+1/snr)) :180-184
-            const cf Zn = (pos && neg) ? zdups : Zs[s];
-            const cf Zp = (pos && neg) ? (Zs[s] - zdups) : Zs[s];
-            const cf Hn = cscale(cmul(rot, Zn), sc);
-            const cf Hp = cscale(cmul(rot, Zp), sc);
-            // chan_est1[synch_bins] = chan_est : a bin listed twice keeps its LAST (positive-half) entry :186-188
-            cf Hk = cf{0.f, 0.f};
-            if (found && neg) Hk = Hn;
-            if (found && pos) Hk = Hp;
-            if (a.htime) lds[k] = Hk;              // natural-order copy for the est_chan_time inverse FFT below
-            if (active) {
-                a.H[int64_t(frame) * N + k] = Hk;
-                if (a.eqg || a.esf) {
-                    // eq_gain = conj(chan_est)/(|chan_est|^2 + 1/snr) (:213-216); est_synch_freq = eq_gain * r (:217-218)
-                    if (neg) {
-                        const cf e = found ? cscale(cconj(Hn), 1.f / (cnorm2(Hn) + rx.inv_snr_eqsync)) : cf{0.f, 0.f};
-                        if (a.eqg) a.eqg[int64_t(frame) * Ks + in_] = e;
-                        if (a.esf && ysc)
-                            for (int LL = 0; LL < rx.S; ++LL)
-                                a.esf[int64_t(frame) * rx.MM + LL * Ks + in_] =
-                                    found ? cmul(e, cscale(cmul(rot, ysc[LL * Ks + in_]), pests)) : cf{0.f, 0.f};
-                    }
-                    if (pos) {
-                        const cf e = found ? cscale(cconj(Hp), 1.f / (cnorm2(Hp) + rx.inv_snr_eqsync)) : cf{0.f, 0.f};
-                        if (a.eqg) a.eqg[int64_t(frame) * Ks + ip_] = e;
-                        if (a.esf && ysc)
-                            for (int LL = 0; LL < rx.S; ++LL)
-                                a.esf[int64_t(frame) * rx.MM + LL * Ks + ip_] =
-                                    found ? cmul(e, cscale(cmul(rot, ysc[LL * Ks + ip_]), pests)) : cf{0.f, 0.f};
-                    }
+            lds[k] = Zs[out_slot<N>(j, kl)];
+            if (Ks == N && k == N / 2) lds[N] = zdups;          // negative-half part of the bin listed twice (K == N)
+        }
+    }
+    wg_barrier();
+    const float sc = pests * rx.inv_ls;                                                 // p_est / (S (1+1/snr)) :180-184
+#pragma unroll 1
+    for (int q = 0; q < P; ++q) {
+        const int k = t + T * q;
+        const cf Zk = lds[k];
+        int in_, ip_;
+        const bool neg = bin_neg(k, Ks, N, in_);
+        const bool pos = bin_pos(k, Ks, ip_);
+        const cf zd = (pos && neg) ? lds[N] : cf{0.f, 0.f};
+        const cf rot = cconj(rx.tw[(dhats * k) & (N - 1)]);                             // e^{+j 2pi d k/N}  :177
+        const cf Hn = cscale(cmul(rot, (pos && neg) ? zd : Zk), sc);
+        const cf Hp = cscale(cmul(rot, (pos && neg) ? (Zk - zd) : Zk), sc);
+        // chan_est1[synch_bins] = chan_est : a bin listed twice keeps its LAST (positive-half) entry :186-188
+        cf Hk = cf{0.f, 0.f};
+        if (found && neg) Hk = Hn;
+        if (found && pos) Hk = Hp;
+        lds[k] = Hk;                               // natural-order H for the est_chan_time inverse FFT below (same lane, same slot)
+        if (active) {
+            a.H[int64_t(frame) * N + k] = Hk;
+            if (a.eqg || a.esf) {
+                // eq_gain = conj(chan_est)/(|chan_est|^2 + 1/snr) (:213-216); est_synch_freq = eq_gain * r (:217-218)
+                if (neg) {
+                    const cf e = found ? cscale(cconj(Hn), 1.f / (cnorm2(Hn) + rx.inv_snr_eqsync)) : cf{0.f, 0.f};
+                    if (a.eqg) a.eqg[int64_t(frame) * Ks + in_] = e;
+                    if (a.esf && ysc)
+                        for (int LL = 0; LL < rx.S; ++LL)
+                            a.esf[int64_t(frame) * rx.MM + LL * Ks + in_] =
+                                found ? cmul(e, cscale(cmul(rot, ysc[LL * Ks + in_]), pests)) : cf{0.f, 0.f};
                 }
-                // data-bin gain: conj(Hd)/(|Hd|^2 + 1/SNR_lin) (:242-246) folded with the lag de-rotation (:237-240)
-                const cf Hg = a.H_for_gain ? a.H_for_gain[int64_t(frame) * N + k] : Hk;
-                const cf gk = cmul(cscale(cconj(Hg), 1.f / (cnorm2(Hg) + rx.inv_snr_data)), rot);
-                int id_;
-                if (bin_neg(k, Kd, N, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
-                if (bin_pos(k, Kd, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
+                if (pos) {
+                    const cf e = found ? cscale(cconj(Hp), 1.f / (cnorm2(Hp) + rx.inv_snr_eqsync)) : cf{0.f, 0.f};
+                    if (a.eqg) a.eqg[int64_t(frame) * Ks + ip_] = e;
+                    if (a.esf && ysc)
+                        for (int LL = 0; LL < rx.S; ++LL)
+                            a.esf[int64_t(frame) * rx.MM + LL * Ks + ip_] =
+                                found ? cmul(e, cscale(cmul(rot, ysc[LL * Ks + ip_]), pests)) : cf{0.f, 0.f};
+                }
             }
+            // data-bin gain: conj(Hd)/(|Hd|^2 + 1/SNR_lin) (:242-246) folded with the lag de-rotation (:237-240)
+            const cf Hg = a.H_for_gain ? a.H_for_gain[int64_t(frame) * N + k] : Hk;
+            const cf gk = cmul(cscale(cconj(Hg), 1.f / (cnorm2(Hg) + rx.inv_snr_data)), rot);
+            int id_;
+            if (bin_neg(k, Kd, N, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
+            if (bin_pos(k, Kd, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
         }
     }
     if (a.htime) {                                                                      // :202,212  ifft(chan_est1)
