@@ -206,10 +206,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world == 1:
-        s_ms, d_ms = rxe.kernel_ms()          # HIP events recorded on the launch stream inside the timed region
-        k_sync.append(s_ms)
-        k_demod.append(d_ms)
+    s_ms, d_ms = rxe.kernel_ms()              # HIP events recorded on the launch stream inside the timed region
+    k_sync.append(s_ms)                       # (mean per launch; N>1 launches one sync+demod pair per sub-batch)
+    k_demod.append(d_ms)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -233,14 +232,14 @@ def main():
         # ---- roofline of the dominant kernel (rx_demod_kernel): algorithmic bytes per launch / measured duration.
         # per data symbol the stream read is L*8 B (CP included), the write Kd*8 B (+ Kd*bps/8 B bits).
         roof = None
-        if world == 1 and k_demod:
-            dsym = n_frames * nds
+        if k_demod:
+            dsym = n_frames * nds // n_chunks                      # data symbols per demod launch (rank 0)
             alg = dsym * (L * 8 + (0 if d_eq is None else Kd * 8) + Kd * bps // 8)
             dm = float(np.mean(k_demod))
             ach = alg / (dm * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r01_demod_traffic.json")
-            if os.path.exists(tf):
+            if world == 1 and os.path.exists(tf):
                 try:
                     traffic = json.load(open(tf)).get(args.config)
                 except Exception:
@@ -260,18 +259,19 @@ def main():
                     e1.synchronize()
                     ts.append(e0.elapsed_time(e1))
                 return float(np.median(ts)), nb
-            cms, cnb = _probe(0)
-            copy_gbs = 2 * cnb / cms / 1e6
-            pat_gbs = None
-            if d_eq is not None:
-                pms, _ = _probe(1)
-                pat_gbs = dsym * (L * 8 + Kd * 8) / pms / 1e6
+            copy_gbs = pat_gbs = None
+            if world == 1:
+                cms, cnb = _probe(0)
+                copy_gbs = 2 * cnb / cms / 1e6
+                if d_eq is not None:
+                    pms, _ = _probe(1)
+                    pat_gbs = dsym * (L * 8 + Kd * 8) / pms / 1e6
             roof = dict(bound="hbm", kernel="rx_demod_kernel<%d>" % N, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                         algorithmic_bytes_per_launch=int(alg), kernel_ms=round(dm, 4),
                         sync_kernel_ms=round(float(np.mean(k_sync)), 4),
                         read_only_frac=round(dsym * L * 8 / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        measured_copy_GBs=round(copy_gbs, 1),
+                        measured_copy_GBs=None if copy_gbs is None else round(copy_gbs, 1),
                         access_pattern_no_math_GBs=None if pat_gbs is None else round(pat_gbs, 1))
         cpu = None
         if world == 1 and not args.no_cpu:
