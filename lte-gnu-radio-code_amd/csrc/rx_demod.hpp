@@ -178,7 +178,7 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
 
     const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
     const int tsr0 = a.tsr[frame * 4 + 0];
-    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
+    // L2IN (experiment only, wrong results): every workgroup reads frame (blockIdx % 8) -> the input stays cache-resident
+    const cf* frame_iq = a.iq + int64_t(L2IN ? (blockIdx.x & 7) : frame) * a.frame_stride;
 
     // the frame's gains -> LDS, once per chunk (Kd even: whole 16 B pairs); published by the FFT's first barrier
     const cf* gain = a.gain + int64_t(frame) * Kd;
@@ -444,6 +445,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             if (a.variant == 2) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, true>), dim3(grid), dim3(DG::WG), DG::lds_bytes(rx.Kd, false), s, rx, a);
             if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 5) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 6) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             return hipGetLastError();
         }
