@@ -465,6 +465,12 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         int64_t p_valid = lim > 0 ? (lim + d.stride - 1) / d.stride : 0;    // number of valid P: P < ceil(lim/stride)
         if (p_valid > n_trials) p_valid = n_trials;
         int64_t p0 = 0;
+        if (h->corr_obs != -1) {
+            // After the first call a trial can only be accepted if P*stride + cp - tsr0 > 2cp + N (:168): earlier trials
+            // are evaluated by the reference but can never win, so they are skipped (identical outcome).
+            const int64_t need = int64_t(h->tsr[0]) + d.cp + N;            // P*stride > need
+            p0 = need >= 0 ? need / d.stride + 1 : 0;
+        }
         int win = 128;
         std::vector<float> tm(ofdm_rx::TRIAL_CAP);
         std::vector<int> td(ofdm_rx::TRIAL_CAP);
