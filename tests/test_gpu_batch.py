@@ -236,3 +236,60 @@ def test_offline_modulator_mirror_reproduces_fixture(om, golden):
     noise = mas.buffer_data_rx_time[0] - orc.channel_apply(mas.buffer_data_tx_time[0], orc.REF_TAPS, N)
     nz = noise[:mas._noise_len]
     assert abs(np.var(nz) / mas.noise_var - 1) < 0.1 and not noise[mas._noise_len:].any()
+
+
+def test_batch_path_is_graph_capturable_and_stream_ordered(om):
+    """ofdm_rx_demod_frames allocates nothing after ofdm_rx_reserve and only enqueues on the caller's stream: it can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; results equal the eager call."""
+    import torch
+    N, cp, Kd, n_sym, n_frames = 1024, 72, 600, 8, 6
+    bits, iq = _frames(N, cp, Kd, n_sym, n_frames, "QPSK", seed=5, tail=0)
+    fl = iq.shape[1]
+    rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+    rx.reserve(n_frames)
+    nds = rx.data_symbols_per_frame(fl)
+    d_iq = torch.from_numpy(iq.view(np.float32).reshape(n_frames, fl, 2)).cuda()
+    d_eq = torch.zeros((n_frames, nds, Kd, 2), dtype=torch.float32, device="cuda")
+    d_b = torch.zeros((n_frames, nds * Kd * 2 // 8), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        rx.demod_frames(d_iq, n_frames, fl, fl, d_eq, d_b, om.BITS_PACKED, None, s.cuda_stream)
+    s.synchronize()
+    eager_eq, eager_b = d_eq.clone(), d_b.clone()
+    assert np.array_equal(np.unpackbits(eager_b.cpu().numpy(), axis=1), bits)
+    d_eq.zero_()
+    d_b.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        rx.demod_frames(d_iq, n_frames, fl, fl, d_eq, d_b, om.BITS_PACKED, None, torch.cuda.current_stream().cuda_stream)
+    assert not d_eq.any()                      # capture enqueues nothing
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(d_eq, eager_eq) and torch.equal(d_b, eager_b)
+
+
+def test_two_handles_run_concurrently_from_threads(om):
+    """GNU Radio runs one thread per block: two handles, two host threads, no shared mutable state in the library."""
+    import threading
+    N, cp, Kd, n_sym = 256, 18, 152, 8
+    results = {}
+
+    def run(idx):
+        bits, iq = _frames(N, cp, Kd, n_sym, 3, "QPSK", seed=100 + idx, tail=0)
+        fl = iq.shape[1]
+        rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+        d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+        nds = rx.data_symbols_per_frame(fl)
+        d_b = om.DeviceBuffer(3 * nds * Kd * 2)
+        ok = True
+        for _ in range(20):
+            rx.demod_frames(d_iq, 3, fl, fl, None, d_b, om.BITS_UNPACKED, None)
+            ok &= np.array_equal(d_b.download(np.uint8, 3 * nds * Kd * 2).reshape(3, -1), bits)
+        results[idx] = ok
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert results == {0: True, 1: True}
