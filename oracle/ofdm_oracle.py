@@ -154,7 +154,8 @@ def bit_recovery(z: np.ndarray):
 
 
 def tx_grid(bits: np.ndarray, nfft: int, num_synch_bins: int, num_data_bins: int,
-            n_sym: int, synch_dat=(1, 3), modulation: str = "QPSK", zc_root: int = 23) -> np.ndarray:
+            n_sym: int, synch_dat=(1, 3), modulation: str = "QPSK", zc_root: int = 23, zc_segments: bool = False,
+            zc_parity_of_bins: bool = False) -> np.ndarray:
     """Resource grid (n_sym, nfft): ZC on sync symbols, mapped data on data symbols.
 
     TX:135-183.  ``synch_state`` never advances (TX:146) so every sync symbol carries
@@ -165,12 +166,19 @@ def tx_grid(bits: np.ndarray, nfft: int, num_synch_bins: int, num_data_bins: int
     sb = bins_p(num_synch_bins, nfft)
     db = bins_p(num_data_bins, nfft)
     zc = zadoff_chu(S * num_synch_bins, zc_root)
+    if zc_parity_of_bins:      # gr-RXOFDM / SynchEstAndFO generation: the ZC form follows the parity of Ks, not of S*Ks
+        mm = S * num_synch_bins
+        t0 = np.arange(mm, dtype=np.float64)
+        zc = np.exp((-1j * (2 * np.pi / mm) * zc_root / 2.0) * (t0 * t0 if num_synch_bins % 2 == 0 else t0 * (t0 + 1)))
     grid = np.zeros((n_sym, nfft), dtype=np.complex128)
     bits = np.asarray(bits).ravel()
     nd = 0
     for s in range(n_sym):
         if s % (S + D) < S:
-            grid[s, sb] = zc[0:num_synch_bins]
+            # reference TX: synch_state never advances -> segment 0 every time (TX:143-147); zc_segments=True sends
+            # the segment the receivers correlate against (needed for synch_dat[0] > 1)
+            seg = (s % (S + D)) if zc_segments else 0
+            grid[s, sb] = zc[seg * num_synch_bins:(seg + 1) * num_synch_bins]
         else:
             chunk = bits[nd * num_data_bins * bps:(nd + 1) * num_data_bins * bps]
             grid[s, db] = map_bits(chunk, modulation)
@@ -195,10 +203,11 @@ def tx_symbol_synth(grid: np.ndarray, cp_len: int) -> np.ndarray:
 
 
 def tx_modulate(bits, nfft, cp_len, num_synch_bins, num_data_bins, n_sym,
-                synch_dat=(1, 3), modulation="QPSK", zc_root=23) -> np.ndarray:
+                synch_dat=(1, 3), modulation="QPSK", zc_root=23, zc_segments=False, zc_parity_of_bins=False) -> np.ndarray:
     """bits -> time-domain IQ (a1+a2+a3)."""
     return tx_symbol_synth(
-        tx_grid(bits, nfft, num_synch_bins, num_data_bins, n_sym, synch_dat, modulation, zc_root), cp_len)
+        tx_grid(bits, nfft, num_synch_bins, num_data_bins, n_sym, synch_dat, modulation, zc_root, zc_segments,
+                zc_parity_of_bins), cp_len)
 
 
 REF_TAPS = np.array([0.3977, 0.7954 - 0.3977j, -0.1988, 0.0994, -0.0398])  # TX:64
@@ -463,3 +472,118 @@ def rx_demod_frames_vectorised(iq: np.ndarray, frame_len: int, cfg: dict) -> np.
         X = X * np.sqrt(len(db) / np.sum(X * np.conj(X), axis=1))[:, None]
         out[f] = X * g[None, :]
     return out
+
+
+# --------------------------------------------------------------------------- CFO-search receiver
+
+# numerology "cases" of G/LEGACY/gr-ofdm-rx/python/SynchEstAndFO.py:36-137
+# (num_ofdm_symb, fs, nfft, synch_dat, num_data_bins); cp_len = nfft/4, num_synch_bins = nfft-2, SNR = 1e8 in every case
+FO_CASES = {
+    0: (48, 960000, 64, (1, 1), 12), 1: (48, 960000, 64, (1, 1), 36), 2: (48, 960000, 64, (1, 1), 48),
+    3: (48, 960000, 64, (2, 1), 48), 4: (48, 960000, 64, (3, 1), 24), 5: (48, 960000, 64, (2, 1), 24),
+    6: (24, 1920000, 128, (3, 1), 24), 7: (24, 1920000, 128, (5, 1), 100), 8: (12, 3840000, 256, (5, 1), 36),
+    9: (12, 3840000, 256, (2, 1), 180),
+}
+
+
+class FoOracle:
+    """fp64 restatement of SynchEstAndFO (FO = G/LEGACY/gr-ofdm-rx/python/SynchEstAndFO.py:28-363), Python-2 semantics
+    (the file's `/` on ints is floor division: cp_len = nfft/4, corr_size = num_ofdm_symb/sum(synch_dat)).
+
+    Differences from SynchAndChanEst that are kept literally: a table of up to 100 syncs per call and no `break` (FO:250-321);
+    one data symbol per sync (FO:324-351); the brute-force carrier-offset search over `fo_range` (FO:261-282); the LS estimate
+    uses the sync vector of the LAST candidate while the lag comes from the best one (FO:268-274,300-301); the data symbols are
+    rotated with the best candidate of the LAST trial evaluated in the call (`dmax_tmp_ind`, FO:284,331)."""
+
+    MAX_CORR = 100
+
+    def __init__(self, case, fo_range, py2_rotators=True):
+        """py2_rotators=True reproduces the only executable semantics of the file: under Python 2, `(1/self.fs)` in FO:192
+        is an INTEGER division (fs is an int) = 0, so every carrier-offset rotator is exp(0) = 1 and the search is a no-op
+        (all candidates tie, index 0 wins).  py2_rotators=False uses 1.0/fs, the evidently intended rotators (unpinned)."""
+        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = FO_CASES[case]
+        self.synch_dat = [int(sd[0]), int(sd[1])]
+        self.cp_len = self.nfft // 4                                         # FO:39 (py2 int division)
+        self.num_synch_bins = self.nfft - 2
+        self.SNR = 100000000
+        self.fo_range = list(fo_range)
+        self.synch_bins_used_P = bins_p(self.num_synch_bins, self.nfft)      # FO:155-158
+        self.bins_used_P = bins_p(self.num_data_bins, self.nfft)             # FO:185-187
+        self.L_synch = len(self.synch_bins_used_P)
+        self.M = [self.synch_dat[0], self.num_synch_bins]
+        self.MM = int(np.prod(self.M))
+        self.p = 37                                                          # FO:167
+        tmp0 = np.arange(self.MM, dtype=np.float64)
+        xx = tmp0 * tmp0 if self.num_synch_bins % 2 == 0 else tmp0 * (tmp0 + 1)     # FO:168-173 (parity of Ks)
+        self.zadoff_chu = np.exp((-1j * (2 * np.pi / self.MM) * self.p / 2.0) * xx)  # FO:175-176
+        inv_fs = (1 // self.fs) if py2_rotators else (1.0 / self.fs)
+        self.cfo = np.exp(1j * 2 * np.pi * inv_fs * np.outer(self.fo_range, np.arange(self.nfft)))         # FO:192
+        self.del_mat_exp = np.tile(np.exp((1j * (2.0 * np.pi / self.nfft)) * np.outer(
+            np.arange(self.cp_len + 1), self.synch_bins_used_P)), (1, self.M[0]))    # FO:193-194
+        self.stride_val = self.cp_len - 1                                    # FO:196
+        self.start_samp = self.cp_len
+        self.rx_b_len = self.nfft + self.cp_len
+        n = self.MAX_CORR
+        self.time_synch_ref = np.zeros((n, 3))                               # FO:202
+        self.est_chan_time = np.zeros((n, self.nfft), dtype=complex)
+        self.est_synch_freq = np.zeros((n, self.MM), dtype=complex)
+        self.est_chan_freq_P = np.zeros((n, self.nfft), dtype=complex)
+        self.est_data_freq = np.zeros((n, self.num_data_bins), dtype=complex)
+        self.cor_obs = -1
+        self.count = 0
+        self.dmax_tmp_ind = None
+        self.eq_gain = None
+
+    def work(self, in0, out):
+        in0 = np.asarray(in0)
+        n_in = len(in0)
+        S, N, L, cp = self.M[0], self.nfft, self.rx_b_len, self.cp_len
+        zc_c = np.conj(self.zadoff_chu)
+        n_trials = int(np.around(n_in / self.stride_val))                    # FO:246
+        for P in range(n_trials):                                            # FO:248
+            if S * L + P * self.stride_val + N + self.start_samp < n_in:     # FO:249
+                win = [in0[L * LL + P * self.stride_val + cp: L * LL + P * self.stride_val + cp + N].astype(np.complex128)
+                       for LL in range(S)]                                   # FO:250-253
+                dmax_ind0 = np.zeros(len(self.fo_range), dtype=int)
+                dmax_val0 = np.zeros(len(self.fo_range))
+                y = None
+                for fo in range(len(self.fo_range)):                         # FO:258
+                    y = np.concatenate([np.fft.fft(win[LL] * self.cfo[fo], N)[self.synch_bins_used_P] for LL in range(S)])
+                    y = y * np.sqrt(len(y) / np.sum(y * np.conj(y)))         # FO:268-270
+                    del_mat = self.del_mat_exp @ (y * zc_c)                  # FO:272-275
+                    dmax_ind0[fo] = np.argmax(np.abs(del_mat))               # FO:277
+                    dmax_val0[fo] = np.max(np.abs(del_mat))                  # FO:278
+                dmax_val = np.max(dmax_val0)                                 # FO:282
+                self.dmax_tmp_ind = int(np.argmax(dmax_val0))                # FO:283
+                dmax_ind = dmax_ind0[self.dmax_tmp_ind]                      # FO:285
+                if dmax_val > 0.4 * self.MM:                                 # FO:288
+                    tim_synch_ind = self.time_synch_ref[max(self.cor_obs, 0)][0]     # FO:289
+                    if (P * self.stride_val + self.start_samp - tim_synch_ind > 2 * cp + N) or self.cor_obs == -1:
+                        self.cor_obs += 1                                    # FO:294 (IndexError past 100 rows)
+                        self.time_synch_ref[self.cor_obs] = [P * self.stride_val + self.start_samp, dmax_ind, int(dmax_val)]
+                        data_recov = self.del_mat_exp[dmax_ind] * y          # FO:300-301: y of the LAST candidate
+                        tmp_v1 = data_recov * zc_c / (1.0 / self.SNR + 1.0)  # FO:303-304
+                        chan_est = np.sum(tmp_v1.reshape(S, self.L_synch), axis=0) / float(S)    # FO:306-307
+                        chan_est1 = np.zeros(N, dtype=complex)
+                        chan_est1[self.synch_bins_used_P] = chan_est         # FO:309-311
+                        self.est_chan_freq_P[self.cor_obs] = chan_est1
+                        self.est_chan_time[self.cor_obs] = np.fft.ifft(chan_est1, N)          # FO:313,323
+                        self.eq_gain = np.conj(chan_est) / (1.0 / self.SNR + chan_est * np.conj(chan_est))   # FO:324-327
+                        self.est_synch_freq[self.cor_obs] = np.tile(self.eq_gain, S) * data_recov           # FO:328-329
+        for P in range(self.cor_obs + 1):                                    # FO:332
+            if self.time_synch_ref[P][0] + S * L + N - 1 <= n_in:            # FO:334
+                data_ptr = int(self.time_synch_ref[P][0] + S * L)            # FO:335
+                x = in0[data_ptr: data_ptr + N] * self.cfo[self.dmax_tmp_ind]    # FO:338-339 (ValueError if the slice is short)
+                t_vec = np.fft.fft(x, N)                                     # FO:340
+                f0 = t_vec[self.bins_used_P]
+                f0 = f0 * np.sqrt(len(f0) / np.dot(f0, np.conj(f0)))         # FO:343-345
+                f0 = f0 * np.exp((1j * (2 * np.pi / N)) * self.time_synch_ref[P][1] * self.bins_used_P)   # FO:347-350
+                hd = self.est_chan_freq_P[P][self.bins_used_P]               # FO:352
+                self.est_data_freq[P] = np.conj(hd) / (1.0 / self.SNR + hd * np.conj(hd)) * f0   # FO:354-358
+        corr_size = self.num_ofdm_symb // sum(self.synch_dat)                # FO:362 (py2 int division)
+        data_out = np.reshape(self.est_data_freq[0:corr_size], (1, corr_size * self.num_data_bins))   # FO:364
+        if self.count > 0:
+            out[0:data_out.shape[1]] = data_out[0]                           # FO:366-367
+        self.count += 1
+        self.cor_obs = 0                                                     # FO:369
+        return len(out)
