@@ -172,6 +172,48 @@ int ofdm_channel_apply(ofdm_tx* h, const float* d_in, int64_t n_frames, int64_t 
                        const float* d_taps, int32_t n_taps, int32_t per_frame_taps, float noise_var,
                        uint64_t seed, float* d_out, int64_t out_stride, int64_t out_len, void* stream);
 
+/* ------------------------------------------------------- CFO-search receiver */
+/* Replaces OFDMReceiver.SynchEstAndFO (G/LEGACY/gr-ofdm-rx/python/SynchEstAndFO.py:28-369): the
+ * gr-RXOFDM receiver (root-37 ZC, stride cp-1, gate 0.4, linear SNR) plus a brute-force carrier
+ * offset search -- every sync trial is evaluated once per candidate rotator (:258-282) -- and a
+ * table of up to OFDM_FO_MAX_SYNC syncs per work() call, each followed by ONE equalised data
+ * symbol (:332-358).  The candidate rotators are handed over as a table so that the caller decides
+ * how `cfo` (:192) is formed (under the file's Python-2 semantics 1/fs is an integer division and
+ * every rotator is 1). */
+#define OFDM_FO_MAX_SYNC 100          /* rows of time_synch_ref / est_chan_freq_P / est_data_freq (:197,202-206) */
+typedef struct ofdm_fo ofdm_fo;
+typedef struct ofdm_fo_cfg {
+    int32_t num_ofdm_symb;     /* :37  only sizes the output: corr_size = num_ofdm_symb / (S+D) rows (:362)      */
+    int32_t nfft;
+    int32_t cp_len;
+    int32_t num_synch_bins;
+    int32_t synch_S, synch_D;
+    int32_t num_data_bins;
+    int32_t n_fo;              /* len(fo_range) >= 1                                                           */
+    double snr;                /* self.SNR (:150), linear                                                      */
+    const float* rotators;     /* host, [n_fo][nfft] complex64 interleaved: self.cfo (:192); copied             */
+    int32_t device;
+    int32_t reserved;
+} ofdm_fo_cfg;
+
+typedef struct ofdm_fo_report {
+    int32_t n_sync;            /* cor_obs + 1 before the end-of-call reset (:369)                               */
+    int32_t count;
+    int32_t dmax_tmp_ind;      /* candidate index of the LAST trial evaluated (:283), -1 if none ever was         */
+    int32_t trials_run;
+    int64_t n_data_items;      /* corr_size * num_data_bins values packed at the head of `out` (when count > 0) */
+} ofdm_fo_report;
+
+int ofdm_fo_create(const ofdm_fo_cfg* cfg, ofdm_fo** out);
+int ofdm_fo_destroy(ofdm_fo* h);
+/* SynchEstAndFO.work (:232-369), host buffers; returns n_out or a negative ofdm_status
+ * (OFDM_ERR_INDEX: a 101st sync, :294-296; OFDM_ERR_SHAPE: short data slice :338-339 / reshape :364). */
+int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, int64_t n_out, ofdm_fo_report* rep);
+/* Block attributes, any pointer may be NULL: h_tsr[100][3] doubles (time_synch_ref), complex64 interleaved
+ * h_chan_freq[100][nfft], h_chan_time[100][nfft], h_synch_freq[100][S*Ks], h_data_freq[100][Kd], h_eq_gain[Ks]. */
+int ofdm_fo_get_state(ofdm_fo* h, double* h_tsr, float* h_chan_freq, float* h_chan_time, float* h_synch_freq,
+                      float* h_data_freq, float* h_eq_gain);
+
 /* ------------------------------------------------------------------------------------------ misc */
 /* Measurement aid for bench.py: mode 0 = float4 device copy of `bytes` (achievable HBM rate of this chip, same run);
  * mode 1 = the demod kernel's access pattern without arithmetic (per symbol: skip gap_bytes, read sym_in_bytes, write

@@ -68,6 +68,43 @@ int dev_alloc(T** p, size_t count) {
     return OFDM_OK;
 }
 
+// Derived constants of a receiver configuration; returns the Zadoff-Chu root.
+int fill_rxdev(const ofdm_rx_cfg& cfg, RxDev& d) {
+    const ofdm_rx_cfg* c = &cfg;
+    const int N = c->nfft, Ks = c->num_synch_bins, Kd = c->num_data_bins, S = c->synch_S;
+    const int MM = S * Ks;
+    d.nfft = N;
+    d.cp = c->cp_len;
+    d.L = N + c->cp_len;
+    d.Ks = Ks;
+    d.Kd = Kd;
+    d.S = S;
+    d.D = c->synch_D;
+    d.MM = MM;
+    d.bps = c->modulation;
+    double snr_ls, snr_eq, snr_data, gate;
+    int root;
+    if (c->compat == OFDM_COMPAT_UTSA) {
+        const double snr_lin = std::pow(10.0, c->snr / 20.0);     // SynchAndChanEst.py:99 (sic: /20)
+        snr_ls = snr_lin;                                          // :180
+        snr_eq = c->snr;                                           // :214 uses the raw argument
+        snr_data = snr_lin;                                        // :245
+        gate = c->scale_factor_gate;                               // :166
+        d.stride = 1;                                              // :77
+        root = 23;                                                 // :52
+    } else {
+        snr_ls = snr_eq = snr_data = c->snr;                       // synch_and_chan_est.py:184,217,247
+        gate = 0.4;                                                // :170
+        d.stride = c->cp_len - 1;                                  // :81
+        root = 37;                                                 // :54
+    }
+    d.gate_mm = float(gate * double(MM));
+    d.inv_ls = float(1.0 / (double(S) * (1.0 + 1.0 / snr_ls)));
+    d.inv_snr_data = float(1.0 / snr_data);
+    d.inv_snr_eqsync = float(1.0 / snr_eq);
+    return root;
+}
+
 }  // namespace
 
 struct ofdm_rx {
@@ -107,6 +144,33 @@ struct ofdm_rx {
     static constexpr int PROF_RING = 32;       // per-call event triples: no host sync inside a timed loop
     hipEvent_t ev[3 * PROF_RING] = {};
     int64_t prof_calls = 0;
+};
+
+struct ofdm_fo {
+    ofdm_fo_cfg cfg{};
+    hipStream_t stream = nullptr;
+    RxDev dev{};
+    cf* d_tw = nullptr;
+    cf* d_zc = nullptr;
+    cf* d_rot = nullptr;                 // [n_fo][N]  self.cfo (SynchEstAndFO.py:192)
+    // ---- block state (SynchEstAndFO.py:197-222)
+    int count = 0;
+    int cor_obs = -1;
+    int dmax_tmp_ind = -1;
+    double tsr[OFDM_FO_MAX_SYNC][3] = {};
+    cf* d_in = nullptr;
+    int64_t in_cap = 0;
+    int* t_tsr = nullptr;                // [100][4]   device copy used by the kernels
+    cf* t_H = nullptr;                   // [100][N]
+    cf* t_htime = nullptr;               // [100][N]
+    cf* t_esf = nullptr;                 // [100][MM]
+    cf* t_gain = nullptr;                // [100][Kd]
+    cf* t_edf = nullptr;                 // [100][Kd]  est_data_freq
+    cf* s_eqg = nullptr;                 // [Ks]
+    cf* s_ysc = nullptr;                 // [MM]
+    float* d_trial_m = nullptr;          // [n_fo * TRIAL_WIN]
+    int* d_trial_d = nullptr;
+    static constexpr int TRIAL_WIN = 256;
 };
 
 struct ofdm_tx {
@@ -237,35 +301,7 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     const int N = c->nfft, Ks = c->num_synch_bins, Kd = c->num_data_bins, S = c->synch_S;
     const int MM = S * Ks;
     RxDev& d = h->dev;
-    d.nfft = N;
-    d.cp = c->cp_len;
-    d.L = N + c->cp_len;
-    d.Ks = Ks;
-    d.Kd = Kd;
-    d.S = S;
-    d.D = c->synch_D;
-    d.MM = MM;
-    d.bps = c->modulation;
-    double snr_ls, snr_eq, snr_data, gate;
-    int root;
-    if (c->compat == OFDM_COMPAT_UTSA) {
-        const double snr_lin = std::pow(10.0, c->snr / 20.0);     // SynchAndChanEst.py:99 (sic: /20)
-        snr_ls = snr_lin;                                          // :180
-        snr_eq = c->snr;                                           // :214 uses the raw argument
-        snr_data = snr_lin;                                        // :245
-        gate = c->scale_factor_gate;                               // :166
-        d.stride = 1;                                              // :77
-        root = 23;                                                 // :52
-    } else {
-        snr_ls = snr_eq = snr_data = c->snr;                       // synch_and_chan_est.py:184,217,247
-        gate = 0.4;                                                // :170
-        d.stride = c->cp_len - 1;                                  // :81
-        root = 37;                                                 // :54
-    }
-    d.gate_mm = float(gate * double(MM));
-    d.inv_ls = float(1.0 / (double(S) * (1.0 + 1.0 / snr_ls)));
-    d.inv_snr_data = float(1.0 / snr_data);
-    d.inv_snr_eqsync = float(1.0 / snr_eq);
+    const int root = fill_rxdev(*c, d);
 
     int rc = OFDM_OK;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -648,6 +684,270 @@ int ofdm_bandwidth_probe(int32_t device, const void* d_in, void* d_out, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------ TX
+// ================================================================== CFO-search receiver
+int ofdm_fo_destroy(ofdm_fo* h) {
+    if (!h) return OFDM_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_tw, h->d_zc, h->d_rot, h->d_in, h->t_tsr, h->t_H, h->t_htime, h->t_esf, h->t_gain,
+                    h->t_edf, h->s_eqg, h->s_ysc, h->d_trial_m, h->d_trial_d};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return OFDM_OK;
+}
+
+int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
+    if (!c || !out) return fail(OFDM_ERR_INVALID, "ofdm_fo_create: null argument");
+    *out = nullptr;
+    if (!supported_nfft(c->nfft)) return fail(OFDM_ERR_INVALID, "nfft=%d unsupported (64,128,...,4096)", c->nfft);
+    if (c->cp_len < 2 || c->cp_len >= c->nfft) return fail(OFDM_ERR_INVALID, "cp_len=%d out of range (stride is cp_len-1)", c->cp_len);
+    if (c->num_synch_bins < 2 || c->num_synch_bins > c->nfft || (c->num_synch_bins & 1))
+        return fail(OFDM_ERR_INVALID, "num_synch_bins=%d must be even and in [2, nfft]", c->num_synch_bins);
+    if (c->num_data_bins < 2 || c->num_data_bins > c->nfft || (c->num_data_bins & 1))
+        return fail(OFDM_ERR_INVALID, "num_data_bins=%d must be even and in [2, nfft]", c->num_data_bins);
+    if (c->synch_S < 1 || c->synch_D < 1) return fail(OFDM_ERR_INVALID, "synch_dat must be [>=1, >=1]");
+    if (c->num_ofdm_symb < 1) return fail(OFDM_ERR_INVALID, "num_ofdm_symb must be >= 1");
+    if (c->n_fo < 1 || !c->rotators) return fail(OFDM_ERR_INVALID, "fo_range must hold at least one candidate");
+    if (!(c->snr > 0.0)) return fail(OFDM_ERR_INVALID, "snr must be > 0 (linear)");
+
+    HIP_TRY(hipSetDevice(c->device));
+    ofdm_fo* h = new (std::nothrow) ofdm_fo();
+    if (!h) return fail(OFDM_ERR_NOMEM, "out of host memory");
+    h->cfg = *c;
+    h->cfg.rotators = nullptr;            // the caller's table is copied below, never kept
+    ofdm_rx_cfg rc_cfg{};
+    rc_cfg.num_ofdm_symb = c->num_ofdm_symb;
+    rc_cfg.nfft = c->nfft;
+    rc_cfg.cp_len = c->cp_len;
+    rc_cfg.num_synch_bins = c->num_synch_bins;
+    rc_cfg.synch_S = c->synch_S;
+    rc_cfg.synch_D = c->synch_D;
+    rc_cfg.num_data_bins = c->num_data_bins;
+    rc_cfg.snr = c->snr;
+    rc_cfg.compat = OFDM_COMPAT_RXOFDM;   // same constants: root 37 (FO:167), stride cp-1 (:196), gate 0.4 (:288), linear SNR
+    rc_cfg.modulation = 2;
+    RxDev& d = h->dev;
+    const int root = fill_rxdev(rc_cfg, d);
+    const int N = d.nfft, Ks = d.Ks, Kd = d.Kd, MM = d.MM;
+    constexpr size_t R = OFDM_FO_MAX_SYNC;
+
+    int rc = OFDM_OK;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = fail(OFDM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    auto tw = make_twiddles(N);
+    auto zc = make_zc(MM, root, Ks);                                  // FO:168-176: parity of num_synch_bins
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_rot, size_t(c->n_fo) * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_tsr, R * 4);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_H, R * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_htime, R * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_esf, R * MM);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_gain, R * Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_edf, R * Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_eqg, size_t(Ks));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_ysc, size_t(MM));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_m, size_t(c->n_fo) * ofdm_fo::TRIAL_WIN);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_d, size_t(c->n_fo) * ofdm_fo::TRIAL_WIN);
+    if (rc == OFDM_OK) {
+        bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_rot, c->rotators, size_t(c->n_fo) * N * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemset(h->t_tsr, 0, R * 4 * sizeof(int)) == hipSuccess &&
+                  hipMemset(h->t_H, 0, R * N * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_htime, 0, R * N * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_esf, 0, R * MM * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_gain, 0, R * Kd * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_edf, 0, R * Kd * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->s_eqg, 0, size_t(Ks) * sizeof(cf)) == hipSuccess;
+        if (!ok) rc = fail(OFDM_ERR_HIP, "device table initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (rc != OFDM_OK) {
+        std::string keep = g_last_error;
+        ofdm_fo_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    d.tw = h->d_tw;
+    d.zc = h->d_zc;
+    *out = h;
+    return OFDM_OK;
+}
+
+int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, int64_t n_out, ofdm_fo_report* rep) {
+    if (!h || (!h_in && n_in > 0) || (!h_out && n_out > 0) || n_in < 0 || n_out < 0)
+        return fail(OFDM_ERR_INVALID, "ofdm_fo_work: bad argument");
+    const RxDev& d = h->dev;
+    const int N = d.nfft, L = d.L, S = d.S, Kd = d.Kd, n_fo = h->cfg.n_fo;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = h->stream;
+
+    if (n_in > h->in_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (h->d_in) (void)hipFree(h->d_in);
+        h->d_in = nullptr;
+        h->in_cap = 0;
+        const int64_t cap = n_in + n_in / 4 + 1024;
+        int rc = dev_alloc(&h->d_in, size_t(cap));
+        if (rc != OFDM_OK) return rc;
+        h->in_cap = cap;
+    }
+    if (n_in > 0) HIP_TRY(hipMemcpyAsync(h->d_in, h_in, size_t(n_in) * sizeof(cf), hipMemcpyHostToDevice, s));
+
+    int trials_run = 0;
+    auto fill_report = [&](int n_sync) {
+        if (!rep) return;
+        rep->n_sync = n_sync;
+        rep->count = h->count;
+        rep->dmax_tmp_ind = h->dmax_tmp_ind;
+        rep->trials_run = trials_run;
+        rep->n_data_items = int64_t(h->cfg.num_ofdm_symb / (d.S + d.D)) * Kd;
+    };
+
+    // ---------------- Loop A: every valid trial, every candidate; NO break (FO:248-329)
+    {
+        const int64_t n_trials = int64_t(std::nearbyint(double(n_in) / double(d.stride)));   // :246
+        const int64_t lim = n_in - (int64_t(S) * L + N + d.cp);                              // :249  P*stride < lim
+        int64_t p_valid = lim > 0 ? (lim + d.stride - 1) / d.stride : 0;
+        if (p_valid > n_trials) p_valid = n_trials;
+        std::vector<float> tm(size_t(n_fo) * ofdm_fo::TRIAL_WIN);
+        std::vector<int> td(size_t(n_fo) * ofdm_fo::TRIAL_WIN);
+        for (int64_t p0 = 0; p0 < p_valid; p0 += ofdm_fo::TRIAL_WIN) {
+            const int cnt = int(std::min<int64_t>(ofdm_fo::TRIAL_WIN, p_valid - p0));
+            SyncArgs sa{};
+            sa.iq = h->d_in;
+            sa.frame_stride = n_in;
+            sa.frame_len = n_in;
+            sa.n_frames = 1;
+            sa.mode = 1;
+            sa.p_begin = int(p0);
+            sa.p_count = cnt;
+            sa.trial_m = h->d_trial_m;
+            sa.trial_d = h->d_trial_d;
+            sa.rot = h->d_rot;
+            sa.n_rot = n_fo;
+            HIP_TRY(launch_rx_sync(d, sa, s));
+            HIP_TRY(hipMemcpyAsync(tm.data(), h->d_trial_m, size_t(cnt) * n_fo * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(td.data(), h->d_trial_d, size_t(cnt) * n_fo * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (int w = 0; w < cnt; ++w) {
+                const int64_t P = p0 + w;
+                ++trials_run;
+                int best = 0;                                                                // :282-285 first maximum wins
+                for (int fo = 1; fo < n_fo; ++fo)
+                    if (tm[size_t(fo) * cnt + w] > tm[size_t(best) * cnt + w]) best = fo;
+                const float dmax_val = tm[size_t(best) * cnt + w];
+                const int dmax_ind = td[size_t(best) * cnt + w];
+                h->dmax_tmp_ind = best;                                                      // :283 (state: the LAST trial's)
+                if (!(dmax_val > d.gate_mm)) continue;                                       // :288
+                const double pos = double(P * d.stride + d.cp);
+                const double ref = h->tsr[h->cor_obs > 0 ? h->cor_obs : 0][0];               // :289
+                if (!(pos - ref > double(2 * d.cp + N) || h->cor_obs == -1)) continue;       // :291
+                h->cor_obs += 1;                                                             // :294
+                if (h->cor_obs >= OFDM_FO_MAX_SYNC) {
+                    fill_report(h->cor_obs);
+                    return fail(OFDM_ERR_INDEX, "time_synch_ref has %d rows, cor_obs=%d (the reference raises IndexError)",
+                                OFDM_FO_MAX_SYNC, h->cor_obs);
+                }
+                const int row = h->cor_obs;
+                h->tsr[row][0] = pos;                                                        // :296-298
+                h->tsr[row][1] = double(dmax_ind);
+                h->tsr[row][2] = double(int(dmax_val));
+                // LS estimate of this sync on the device: sync vector of the LAST candidate, lag of the best one (:300-329)
+                SyncArgs fa{};
+                fa.iq = h->d_in;
+                fa.frame_stride = n_in;
+                fa.frame_len = n_in;
+                fa.n_frames = 1;
+                fa.mode = 0;
+                fa.p_begin = int(P);
+                fa.p_count = 1;
+                fa.force_accept = 1;
+                fa.rot = h->d_rot + size_t(n_fo - 1) * N;
+                fa.n_rot = 1;
+                fa.force_dhat_p1 = dmax_ind + 1;
+                fa.tsr = h->t_tsr + size_t(row) * 4;
+                fa.H = h->t_H + size_t(row) * N;
+                fa.H_for_gain = nullptr;                                                     // :352 own row
+                fa.gain = h->t_gain + size_t(row) * Kd;
+                fa.htime = h->t_htime + size_t(row) * N;
+                fa.esf = h->t_esf + size_t(row) * d.MM;
+                fa.eqg = h->s_eqg;
+                fa.yscratch = h->s_ysc;
+                HIP_TRY(launch_rx_sync(d, fa, s));
+            }
+        }
+    }
+    const int n_sync = h->cor_obs + 1;
+    fill_report(n_sync);
+
+    // ---------------- Loop B: one data symbol per sync (FO:332-358)
+    if (n_sync > 0) {
+        for (int r = 0; r < n_sync; ++r) {
+            const int64_t ptr = int64_t(h->tsr[r][0]) + int64_t(S) * L;                      // :335
+            if (ptr + N - 1 <= n_in && ptr + N > n_in)                                       // :334 passes, slice has N-1 items
+                return fail(OFDM_ERR_SHAPE, "data window of sync %d is one sample short (the reference raises ValueError)", r);
+        }
+        if (h->dmax_tmp_ind < 0)
+            return fail(OFDM_ERR_INVALID, "no trial has ever been evaluated: dmax_tmp_ind is undefined (the reference raises NameError)");
+        DemodArgs da{};
+        da.iq = h->d_in;
+        da.frame_stride = 0;                    // every "frame" is the same buffer seen from another sync
+        da.frame_len = n_in;
+        da.n_frames = n_sync;
+        da.tsr = h->t_tsr;
+        da.gain = h->t_gain;
+        da.eq = h->t_edf;
+        da.bits = nullptr;
+        da.bits_mode = 0;
+        da.mod = 2;
+        da.n_dsym = 1;
+        da.spc = 0;
+        da.chunks_per_frame = 0;
+        da.row_stride_pat = 1;
+        da.rows_per_frame = 1;
+        da.zero_skipped = 0;
+        da.rot = h->d_rot + size_t(h->dmax_tmp_ind) * N;                                     // :339
+        HIP_TRY(launch_rx_demod(d, da, s));
+    }
+
+    // ---------------- output (:362-367)
+    const int64_t corr_size = h->cfg.num_ofdm_symb / (d.S + d.D);
+    if (corr_size > OFDM_FO_MAX_SYNC)
+        return fail(OFDM_ERR_SHAPE, "corr_size=%lld exceeds the %d est_data_freq rows (the reference raises ValueError)",
+                    (long long)corr_size, OFDM_FO_MAX_SYNC);
+    if (h->count > 0) {
+        if (corr_size * Kd > n_out)
+            return fail(OFDM_ERR_SHAPE, "output buffer holds %lld items, need %lld (the reference raises ValueError)",
+                        (long long)n_out, (long long)(corr_size * Kd));
+        HIP_TRY(hipMemcpyAsync(h_out, h->t_edf, size_t(corr_size) * Kd * sizeof(cf), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    h->count += 1;                                                                           // :368
+    h->cor_obs = 0;                                                                          // :369
+    fill_report(n_sync);
+    return n_out;
+}
+
+int ofdm_fo_get_state(ofdm_fo* h, double* h_tsr, float* h_chan_freq, float* h_chan_time, float* h_synch_freq,
+                      float* h_data_freq, float* h_eq_gain) {
+    if (!h) return fail(OFDM_ERR_INVALID, "ofdm_fo_get_state: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const RxDev& d = h->dev;
+    constexpr size_t R = OFDM_FO_MAX_SYNC;
+    if (h_tsr) std::memcpy(h_tsr, h->tsr, sizeof(h->tsr));
+    if (h_chan_freq) HIP_TRY(hipMemcpy(h_chan_freq, h->t_H, R * d.nfft * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_chan_time) HIP_TRY(hipMemcpy(h_chan_time, h->t_htime, R * d.nfft * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_synch_freq) HIP_TRY(hipMemcpy(h_synch_freq, h->t_esf, R * d.MM * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_data_freq) HIP_TRY(hipMemcpy(h_data_freq, h->t_edf, R * d.Kd * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_eq_gain) HIP_TRY(hipMemcpy(h_eq_gain, h->s_eqg, size_t(d.Ks) * sizeof(cf), hipMemcpyDeviceToHost));
+    return OFDM_OK;
+}
+
+// ================================================================== TX
 int ofdm_tx_destroy(ofdm_tx* h) {
     if (!h) return OFDM_OK;
     (void)hipSetDevice(h->cfg.device);

@@ -26,6 +26,7 @@ struct DemodArgs {
     int zero_skipped;        // write zeros for patterns whose guard fails (batch mode)
     int variant;             // kernel tuning variant (0 = default)
     unsigned* stamps;        // diagnostic variant 9: [workgroups][waves][8] phase cycle sums, or null
+    const cf* rot;           // per-sample rotator e^{j 2pi fo n/fs} [nfft] applied to every window (CFO receiver), or null
 };
 
 // ---- RX sync search + LS estimate (reference: SynchAndChanEst.py:143-219, "Loop A") -----------
@@ -46,8 +47,11 @@ struct SyncArgs {
     cf* esf;                 // [n_frames][MM]  est_synch_freq row, or null
     cf* eqg;                 // [n_frames][Ks]  eq_gain, or null
     cf* yscratch;            // [n_frames][MM]  raw sync-bin values of the current trial (needed for esf), or null
-    float* trial_m;          // mode 1: [p_count] max|corr| (-1 = trial not valid)
-    int* trial_d;            // mode 1: [p_count] argmax lag
+    float* trial_m;          // mode 1: [n_rot*p_count] max|corr| (-1 = trial not valid), candidate-major
+    int* trial_d;            // mode 1: [n_rot*p_count] argmax lag
+    const cf* rot;           // carrier-offset rotators [n_rot][nfft] (mode 1) / the one rotator of the finalize (mode 0), or null
+    int n_rot;               // mode 1: candidates per trial (0 or 1 = plain)
+    int force_dhat_p1;       // mode 0: lag+1 that replaces the trial's own arg-max lag (SynchEstAndFO.py:285,300); 0 = off
 };
 
 struct DemapArgs {

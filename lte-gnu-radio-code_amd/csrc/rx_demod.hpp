@@ -178,7 +178,7 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
@@ -256,6 +256,10 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
             const cf* src = frame_iq + sy.start + t;
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) v[n0] = NT ? __builtin_nontemporal_load(src + T * n0) : src[T * n0];
+            if constexpr (ROT) {                                         // data_buff_time * cfo[idx]  (SynchEstAndFO.py:339)
+#pragma unroll
+                for (int n0 = 0; n0 < P; ++n0) v[n0] = cmul(v[n0], a.rot[t + T * n0]);
+            }
         } else {                                                         // short tail: fft(x, N) zero-pads (:230)
             const int64_t last = a.frame_len > 0 ? a.frame_len - 1 : 0;
             const bool any = sy.compute && a.frame_len > 0;
@@ -264,6 +268,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 const int64_t idx = sy.start + t + T * n0;
                 const cf x = any ? frame_iq[idx < last ? idx : last] : cf{0.f, 0.f};
                 v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
+                if constexpr (ROT) v[n0] = cmul(v[n0], a.rot[t + T * n0]);
             }
         }
     };
@@ -439,6 +444,11 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     size_t lds = DG::lds_bytes(rx.Kd, true);
     if (a.variant >= 100) lds += size_t(a.variant - 100) * 1024;   // occupancy experiment: pad the LDS request by (variant-100) KiB
     const int bmode = a.bits ? a.bits_mode : 0;
+    if (a.rot) {                    // CFO receiver: equalised symbols only
+        if (bmode != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, true, false, true, false, true, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+        return hipGetLastError();
+    }
     if constexpr (N == 2048) {      // tuning variants (ofdm_rx_set_variant): 16-QAM packed only
         if (a.variant != 0 && a.variant < 100 && bmode == 1 && a.mod == 4) {
             if (a.variant == 1) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);

@@ -22,7 +22,7 @@ template <int N>
 __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, int64_t frame_len, bool active,
                                            int Ptrial, cf* lds, float* red, const LaneTwiddles<N>& tw, const cf* w1tab, int t,
                                            cf (&Z)[Plan<N>::P], cf& zdup, float& p_est, float& m, int& dhat,
-                                           cf* yscratch) {
+                                           cf* yscratch, const cf* rot = nullptr) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     int* redi = reinterpret_cast<int*>(red) + 8;
@@ -37,6 +37,7 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
         for (int n0 = 0; n0 < P; ++n0) {
             const int64_t idx = w0 + t + T * n0;
             v[n0] = (active && idx < frame_len) ? frame_iq[idx] : cf{0.f, 0.f};
+            if (rot) v[n0] = cmul(v[n0], rot[t + T * n0]);          // sig_with_fo = dat_time * cfo[fo]  (SynchEstAndFO.py:264)
         }
         wg_fft<N>(v, lds, tw, w1tab, t);                                                       // :152
         int Ks_ = rx.Ks;                      // opaque per segment: keeps the 32 per-slot table offsets out of long-lived VGPRs
@@ -125,14 +126,17 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
 
     if (a.mode == 1) {
         // ---- trial table for the stream block: unit = trial index, frame 0
-        const bool active = unit < a.p_count;
-        const int Ptrial = a.p_begin + int(unit);
+        const int n_rot = a.n_rot > 1 ? a.n_rot : 1;
+        const bool active = unit < int64_t(a.p_count) * n_rot;
+        const int cand = active ? int(unit / a.p_count) : 0;            // candidate-major: unit = cand * p_count + w
+        const int Ptrial = a.p_begin + int(unit % a.p_count);
+        const cf* rot = a.rot ? a.rot + int64_t(cand) * N : nullptr;
         const bool valid = active && (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);  // :144
         cf Z[P];
         cf zdup;
         float p_est, m;
         int dhat;
-        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr);
+        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr, rot);
         if (active && t == 0) {
             a.trial_m[unit] = valid ? m : -1.f;
             a.trial_d[unit] = valid ? dhat : 0;
@@ -159,7 +163,8 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
             const bool valid = active && (a.p_count <= 0 || it < a.p_count) &&
                                (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
             if (!valid) break;
-            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc);
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc, a.rot);
+            if (a.force_dhat_p1 > 0) dhats = a.force_dhat_p1 - 1;
             if (a.force_accept || ms > rx.gate_mm) {                                    // :166
                 found = true;
                 Phit = Ptrial;
@@ -186,7 +191,8 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
             cf zdup;
             float p_est, m;
             int dhat;
-            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc);
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc, a.rot);
+            if (a.force_dhat_p1 > 0) dhat = a.force_dhat_p1 - 1;
             if (valid && (a.force_accept || m > rx.gate_mm)) {                          // :166
                 found = true;
 #pragma unroll
@@ -353,7 +359,7 @@ __global__ void __launch_bounds__(256) demap_soft_kernel(DemapArgs a) {
 // ------------------------------------------------------------------------------------------ launchers
 template <int N>
 static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
-    const int64_t units = (a.mode == 1) ? a.p_count : a.n_frames;
+    const int64_t units = (a.mode == 1) ? int64_t(a.p_count) * (a.n_rot > 1 ? a.n_rot : 1) : a.n_frames;
     const unsigned grid = unsigned((units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(rx_sync_kernel<N>, dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);

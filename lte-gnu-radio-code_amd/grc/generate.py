@@ -45,6 +45,11 @@ BLOCKS = [
          cls="BitRecovery",
          params=[("modulation", "Modulation", "string"), ("directory_name", "Directory", "string"), ("diagnostics", "Diagnostics", "int")],
          make_args=["modulation", "directory_name", "diagnostics"], inputs=CPLX_IN, outputs=None),
+    dict(id="OFDMReceiver_SynchEstAndFO", label="SynchEstAndFO (MI355X)", category="[OFDMReceiver]", module="OFDMReceiver",
+         cls="SynchEstAndFO",
+         params=[("case", "Case Number", "int"), ("fo_range", "F Offset Range", "raw"), ("directory_name", "Directory Path", "string"),
+                 ("file_name_cest", "Var: Chan Est -- File Name", "string"), ("diagnostics", "Diagnostics", "int")],
+         make_args=["case", "fo_range", "directory_name", "file_name_cest", "diagnostics"], inputs=CPLX_IN, outputs=CPLX_IN),
 ]
 
 
@@ -55,9 +60,9 @@ def block_yaml(b):
                               make="%s.%s(%s)" % (b["module"], b["cls"], ", ".join("${%s}" % a for a in b["make_args"]))),
                file_format=1)
     if b["inputs"]:
-        doc["inputs"] = b["inputs"]
+        doc["inputs"] = [dict(x) for x in b["inputs"]]
     if b["outputs"]:
-        doc["outputs"] = b["outputs"]
+        doc["outputs"] = [dict(x) for x in b["outputs"]]
     return yaml.safe_dump(doc, sort_keys=False)
 
 

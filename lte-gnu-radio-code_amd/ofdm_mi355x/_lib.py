@@ -50,6 +50,20 @@ class TxCfg(C.Structure):
                 ("modulation", C.c_int32), ("zc_root", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
+class FoCfg(C.Structure):
+    _fields_ = [("num_ofdm_symb", C.c_int32), ("nfft", C.c_int32), ("cp_len", C.c_int32),
+                ("num_synch_bins", C.c_int32), ("synch_S", C.c_int32), ("synch_D", C.c_int32),
+                ("num_data_bins", C.c_int32), ("n_fo", C.c_int32), ("snr", C.c_double),
+                ("rotators", C.c_void_p), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class FoReport(C.Structure):
+    _fields_ = [("n_sync", C.c_int32), ("count", C.c_int32), ("dmax_tmp_ind", C.c_int32), ("trials_run", C.c_int32),
+                ("n_data_items", C.c_int64)]
+
+
+FO_MAX_SYNC = 100
+
 # name -> (restype, argtypes): exactly the prototypes of include/ofdm_mi355x.h
 PROTOTYPES = {
     "ofdm_abi_version": (C.c_int, []),
@@ -75,6 +89,10 @@ PROTOTYPES = {
     "ofdm_rx_set_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "ofdm_rx_set_stamp_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ofdm_demap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofdm_fo_create": (C.c_int, [C.POINTER(FoCfg), C.POINTER(C.c_void_p)]),
+    "ofdm_fo_destroy": (C.c_int, [C.c_void_p]),
+    "ofdm_fo_work": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(FoReport)]),
+    "ofdm_fo_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofdm_tx_create": (C.c_int, [C.POINTER(TxCfg), C.POINTER(C.c_void_p)]),
     "ofdm_tx_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_tx_modulate_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,

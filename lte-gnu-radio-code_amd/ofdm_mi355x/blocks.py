@@ -16,7 +16,7 @@ import pickle
 import numpy as np
 
 from . import _lib
-from .engine import DeviceBuffer, RxEngine, bins_p, zadoff_chu
+from .engine import DeviceBuffer, FoEngine, RxEngine, bins_p, zadoff_chu
 from .gr_compat import sync_block
 from .safe_pickle import load_ndarray
 
@@ -134,6 +134,109 @@ class synch_and_chan_est(SynchAndChanEst):  # noqa: N801  (reference class name)
         SynchAndChanEst.__init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
                                  0.4, directory_name, file_name_cest, diagnostics, genie)
         self.diagnostics = diagnostics
+
+
+# numerology of SynchEstAndFO's `case` argument (LEGACY/gr-ofdm-rx/python/SynchEstAndFO.py:36-135):
+# case -> (num_ofdm_symb, fs, nfft, synch_dat, num_data_bins); cp_len = nfft/4, num_synch_bins = nfft-2, SNR = 1e8
+_FO_CASES = {
+    0: (48, 960000, 64, [1, 1], 12), 1: (48, 960000, 64, [1, 1], 36), 2: (48, 960000, 64, [1, 1], 48),
+    3: (48, 960000, 64, [2, 1], 48), 4: (48, 960000, 64, [3, 1], 24), 5: (48, 960000, 64, [2, 1], 24),
+    6: (24, 1920000, 128, [3, 1], 24), 7: (24, 1920000, 128, [5, 1], 100), 8: (12, 3840000, 256, [5, 1], 36),
+    9: (12, 3840000, 256, [2, 1], 180),
+}
+
+
+class SynchEstAndFO(sync_block):
+    """OFDMReceiver.SynchEstAndFO(case, fo_range, directory_name, file_name_cest, diagnostics) -- ZC timing sync with a
+    brute-force carrier-offset search, a table of up to 100 syncs per call, one equalised data symbol per sync.
+
+    The reference file is Python-2 code (`self.cp_len = self.nfft/4` is used as an index, :39,193): its `/` on ints is a
+    floor division, which also makes `(1/self.fs)` in :192 equal 0 -- every candidate rotator is exp(0) = 1 and the
+    search always picks index 0.  `py2_rotators=True` (default) keeps exactly that; `py2_rotators=False` builds the
+    evidently intended rotators exp(j 2 pi fo n / fs) (no reference output exists for it).
+    """
+
+    def __init__(self, case, fo_range, directory_name, file_name_cest, diagnostics, py2_rotators=True):
+        sync_block.__init__(self, name="SynchEstAndFO", in_sig=[np.complex64], out_sig=[np.complex64])
+        self.case = case
+        if case not in _FO_CASES:
+            # :136 prints "Error: Case Out of Bounds" and then fails on the first missing attribute
+            print("Error: Case Out of Bounds")
+            raise AttributeError("'SynchEstAndFO' object has no attribute 'num_synch_bins'")
+        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = _FO_CASES[case]
+        self.synch_dat = list(sd)
+        self.cp_len = self.nfft // 4
+        self.num_synch_bins = self.nfft - 2
+        self.SNR = 100000000
+        self.fo_range = fo_range
+        self.synch_bins_used_P = list(bins_p(self.num_synch_bins, self.nfft))   # :155-158
+        self.bins_used_P = list(bins_p(self.num_data_bins, self.nfft))          # :185-187
+        self.L_synch = len(self.synch_bins_used_P)
+        self.M = [self.synch_dat[0], self.num_synch_bins]
+        self.MM = int(np.prod(self.M))
+        self.p = 37                                                             # :167
+        self.zadoff_chu = zadoff_chu(self.MM, self.p, parity_of=self.num_synch_bins)
+        inv_fs = (1 // self.fs) if py2_rotators else (1.0 / self.fs)
+        self.cfo = np.exp(1j * 2 * np.pi * inv_fs * np.outer(list(fo_range), np.arange(self.nfft)))   # :192
+        self.stride_val = self.cp_len - 1                                       # :196
+        self.start_samp = self.cp_len
+        self.rx_b_len = self.nfft + self.cp_len
+        self.max_num_corr = _lib.FO_MAX_SYNC                                    # :200
+        self.cor_obs = -1
+        self.count = 0
+        self.directory_name = directory_name
+        self.file_name_cest = file_name_cest
+        self.diagnostics = diagnostics
+        self._engine = FoEngine(self.num_ofdm_symb, self.nfft, self.cp_len, self.num_synch_bins, self.synch_dat,
+                                self.num_data_bins, self.SNR, self.cfo, device=_device())
+        self._n_sync = 0
+
+    def _state(self, key):
+        return self._engine.state()[key]
+
+    @property
+    def time_synch_ref(self):
+        return self._state("time_synch_ref")
+
+    @property
+    def est_chan_freq_P(self):
+        return self._state("chan_freq").astype(complex)
+
+    @property
+    def est_chan_time(self):
+        return self._state("chan_time").astype(complex)
+
+    @property
+    def est_synch_freq(self):
+        return self._state("synch_freq").astype(complex)
+
+    @property
+    def est_data_freq(self):
+        return self._state("data_freq").astype(complex)
+
+    @property
+    def eq_gain(self):
+        return self._state("eq_gain").astype(complex)
+
+    def work(self, input_items, output_items):
+        in0 = input_items[0]
+        out = output_items[0]
+        rc = self._engine.work(in0, out)
+        rep = self._engine.report
+        self.count = rep.count
+        self._n_sync = rep.n_sync
+        if rep.dmax_tmp_ind >= 0:
+            self.dmax_tmp_ind = rep.dmax_tmp_ind                                # :283 (absent until a trial has run)
+        if rc >= 0:
+            self.cor_obs = 0                                                    # :369
+        n = _lib.check(rc)
+        if self.diagnostics == 1 and rep.n_sync > 0:                            # :308-314: dump of the latest estimate
+            import datetime
+            chan_est_tim = self.est_chan_time[rep.n_sync - 1][np.newaxis, :]
+            date_time = datetime.datetime.now().strftime('%Y_%m_%d_%Hh_%Mm')
+            with open(str(self.directory_name) + str(self.file_name_cest) + date_time + '.pckl', 'wb') as f:
+                pickle.dump(chan_est_tim, f, protocol=2)
+        return n
 
 
 def _load_iq_file(path: str) -> np.ndarray:

@@ -165,6 +165,60 @@ class RxEngine:
             pass
 
 
+class FoEngine:
+    """CFO-search receiver handle (reference: LEGACY/gr-ofdm-rx/python/SynchEstAndFO.py): trial x candidate sync table,
+    up to 100 syncs per call, one equalised data symbol per sync."""
+
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, rotators, device=0):
+        self.lib = _lib.load()
+        rot = np.ascontiguousarray(rotators, dtype=np.complex64)
+        if rot.ndim != 2 or rot.shape[1] != int(nfft) or rot.shape[0] < 1:
+            raise ValueError("rotators must be [len(fo_range) >= 1][nfft]")
+        self.cfg = _lib.FoCfg(int(num_ofdm_symb), int(nfft), int(cp_len), int(num_synch_bins), int(synch_dat[0]),
+                              int(synch_dat[1]), int(num_data_bins), int(rot.shape[0]), float(snr),
+                              rot.ctypes.data, int(device), 0)
+        h = C.c_void_p()
+        check(self.lib.ofdm_fo_create(C.byref(self.cfg), C.byref(h)))
+        self.cfg.rotators = None          # the library copied the table
+        self._h = h
+        self.report = _lib.FoReport()
+
+    def work(self, in0: np.ndarray, out: np.ndarray) -> int:
+        """Raw status (see RxEngine.work)."""
+        in0 = np.ascontiguousarray(in0, dtype=np.complex64)
+        if out.dtype != np.complex64 or not out.flags.c_contiguous:
+            tmp = np.ascontiguousarray(out, dtype=np.complex64)
+            rc = self.lib.ofdm_fo_work(self._h, ptr(in0), in0.size, ptr(tmp), tmp.size, C.byref(self.report))
+            if rc >= 0:
+                out[...] = tmp
+            return int(rc)
+        return int(self.lib.ofdm_fo_work(self._h, ptr(in0), in0.size, ptr(out), out.size, C.byref(self.report)))
+
+    def state(self):
+        c = self.cfg
+        R = _lib.FO_MAX_SYNC
+        mm = c.synch_S * c.num_synch_bins
+        tsr = np.zeros((R, 3), np.float64)
+        H = np.zeros((R, c.nfft), np.complex64)
+        ht = np.zeros((R, c.nfft), np.complex64)
+        esf = np.zeros((R, mm), np.complex64)
+        edf = np.zeros((R, c.num_data_bins), np.complex64)
+        eqg = np.zeros(c.num_synch_bins, np.complex64)
+        check(self.lib.ofdm_fo_get_state(self._h, ptr(tsr), ptr(H), ptr(ht), ptr(esf), ptr(edf), ptr(eqg)))
+        return dict(time_synch_ref=tsr, chan_freq=H, chan_time=ht, synch_freq=esf, data_freq=edf, eq_gain=eqg)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ofdm_fo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TxEngine:
     """Transmit chain handle (bit map, resource grid + ZC sync symbols, IFFT + CP + normalise) and channel."""
 
