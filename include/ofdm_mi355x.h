@@ -137,7 +137,9 @@ int ofdm_rx_reserve(ofdm_rx* h, int64_t n_frames);
 /* ------------------------------------------------------------------------------------------ de-map
  * Replaces BitRecovery.work (G/LEGACY/gr-ofdm-rx/python/BitRecovery.py:66-189) on device buffers.
  * d_sym: n complex64; d_hard: n*bps bytes (one bit per byte, order [b0,b1,..] per symbol), may be NULL;
- * d_soft0/d_soft1: n*bps float32 max-log metrics llrp0/llrp1 (:105-125, QPSK only), may be NULL. */
+ * d_soft0/d_soft1: n*bps float32 max-log metrics llrp0/llrp1, may be NULL: QPSK literally as :105-125; 16/64-QAM
+ * (modulation 4/6) by the same rule per axis -- -0.5/sigma^2 * distance to the nearest PAM level carrying bit value
+ * 0 / 1, sigma = 0.7071*mean(dmin) over the buffer (:88,102) -- an extension the reference does not have. */
 int ofdm_demap(ofdm_rx* h, const float* d_sym, int64_t n, int32_t modulation, uint8_t* d_hard,
                float* d_soft0, float* d_soft1, void* stream);
 

@@ -658,8 +658,8 @@ int ofdm_demap(ofdm_rx* h, const float* d_sym, int64_t n, int32_t modulation, ui
     if (!h || (!d_sym && n > 0) || n < 0) return fail(OFDM_ERR_INVALID, "ofdm_demap: bad argument");
     if (modulation != 1 && modulation != 2 && modulation != 4 && modulation != 6)
         return fail(OFDM_ERR_INVALID, "modulation must be 1, 2, 4 or 6 bits per symbol");
-    if ((d_soft0 || d_soft1) && modulation != 2)
-        return fail(OFDM_ERR_INVALID, "soft metrics follow BitRecovery.py (QPSK only)");
+    if ((d_soft0 || d_soft1) && modulation == 1)
+        return fail(OFDM_ERR_INVALID, "soft metrics: QPSK (BitRecovery.py) and its 16/64-QAM extension only");
     HIP_TRY(hipSetDevice(h->cfg.device));
     DemapArgs a{};
     a.sym = reinterpret_cast<const cf*>(d_sym);

@@ -356,6 +356,97 @@ __global__ void __launch_bounds__(256) demap_soft_kernel(DemapArgs a) {
     }
 }
 
+// ---- 16/64-QAM extension of the soft metric (no reference code: BitRecovery.py knows QPSK only).
+// Same structure as BitRecovery.work: sigma = 0.7071 * mean distance to the nearest point over the buffer, per-bit
+// metrics -0.5/sigma^2 * (linear distance), taken per axis to the nearest PAM level that carries bit value 0 / 1.
+// Axis levels l_q = (2q - (M-1)) * u, q = 0..M-1, M = 4 (u = 1/sqrt(10)) or 8 (u = 1/sqrt(42)); TS 36.211 7.1 labels:
+// bit 0 = (l < 0); 16-QAM bit 1 = (|m| == 3); 64-QAM bit 1 = (|m| > 4), bit 2 = (|m| == 1 or 7), m = 2q-(M-1).
+template <int BPS>
+struct Pam {
+    static constexpr int M = BPS == 4 ? 4 : 8;
+    static constexpr int NB = BPS / 2;
+    static __device__ __forceinline__ float unit() { return BPS == 4 ? 0.31622776601683794f : 0.15430334996209191f; }
+    static __device__ __forceinline__ bool label(int q, int j) {
+        const int m = 2 * q - (M - 1), am = m < 0 ? -m : m;
+        if (j == 0) return m < 0;
+        if (BPS == 4) return am == 3;
+        return j == 1 ? am > 4 : (am == 1 || am == 7);
+    }
+    // distances from coordinate x to the nearest level with axis bit j = 0 / 1, and to the nearest level overall
+    static __device__ __forceinline__ void dist(float x, float (&d0)[NB], float (&d1)[NB], float& e) {
+        const float u = unit();
+        e = 3.0e38f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) d0[j] = d1[j] = 3.0e38f;
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            const float d = fabsf(x - float(2 * q - (M - 1)) * u);
+            e = fminf(e, d);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (label(q, j))
+                    d1[j] = fminf(d1[j], d);
+                else
+                    d0[j] = fminf(d0[j], d);
+            }
+        }
+    }
+};
+
+template <int BPS>
+__global__ void __launch_bounds__(256) demap_dmin_qam_kernel(DemapArgs a) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+        const cf z = a.sym[i];
+        float d0[Pam<BPS>::NB], d1[Pam<BPS>::NB], ex, ey;
+        Pam<BPS>::dist(z.x, d0, d1, ex);
+        Pam<BPS>::dist(z.y, d0, d1, ey);
+        acc += double(sqrtf(ex * ex + ey * ey));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0];
+}
+
+template <int BPS>
+__global__ void __launch_bounds__(256) demap_soft_qam_kernel(DemapArgs a) {
+    __shared__ double sh_tot;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < DEMAP_PARTIALS; ++i) s += a.partial[i];
+        sh_tot = s;
+    }
+    __syncthreads();
+    const double sigma = 0.7071067811865476 * (sh_tot / double(a.n));
+    const float hf = float(-0.5 / (sigma * sigma));
+    constexpr int NB = Pam<BPS>::NB;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+        const cf z = a.sym[i];
+        float r0[NB], r1[NB], i0[NB], i1[NB], e;
+        Pam<BPS>::dist(z.x, r0, r1, e);
+        Pam<BPS>::dist(z.y, i0, i1, e);
+        float o0[BPS], o1[BPS];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            o0[2 * j] = hf * r0[j];
+            o0[2 * j + 1] = hf * i0[j];
+            o1[2 * j] = hf * r1[j];
+            o1[2 * j + 1] = hf * i1[j];
+        }
+        // BPS floats per symbol = 16 B (16-QAM) / 24 B (64-QAM), 8-byte aligned: float2 stores
+#pragma unroll
+        for (int b = 0; b < BPS; b += 2) {
+            if (a.soft0) *reinterpret_cast<float2*>(a.soft0 + i * BPS + b) = make_float2(o0[b], o0[b + 1]);
+            if (a.soft1) *reinterpret_cast<float2*>(a.soft1 + i * BPS + b) = make_float2(o1[b], o1[b + 1]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 template <int N>
 static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
@@ -408,8 +499,18 @@ hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
     const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 2048));
     if (a.hard) hipLaunchKernelGGL(demap_hard_kernel, dim3(grid), dim3(256), 0, s, a);
     if (a.soft0 || a.soft1) {
-        hipLaunchKernelGGL(demap_dmin_kernel, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
+        if (a.mod == 2) {
+            hipLaunchKernelGGL(demap_dmin_kernel, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
+        } else if (a.mod == 4) {
+            hipLaunchKernelGGL(demap_dmin_qam_kernel<4>, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_soft_qam_kernel<4>, dim3(grid), dim3(256), 0, s, a);
+        } else if (a.mod == 6) {
+            hipLaunchKernelGGL(demap_dmin_qam_kernel<6>, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_soft_qam_kernel<6>, dim3(grid), dim3(256), 0, s, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

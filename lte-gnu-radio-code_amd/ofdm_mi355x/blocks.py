@@ -274,7 +274,8 @@ class tx_signal_transmitter(TxSignalTransmitter):  # noqa: N801
 
 
 class BitRecovery(sync_block):
-    """OFDMReceiver.BitRecovery -- QPSK hard decisions + max-log soft metrics (sink block)."""
+    """OFDMReceiver.BitRecovery -- hard decisions + max-log soft metrics (sink block).  QPSK follows the reference
+    literally; "16QAM" / "64QAM" use the same metric on the TS 36.211 maps (extension, no reference code)."""
 
     def __init__(self, modulation, directory_name, diagnostics):
         sync_block.__init__(self, name="BitRecovery", in_sig=[np.complex64], out_sig=None)
@@ -295,7 +296,7 @@ class BitRecovery(sync_block):
         dev = self._engine.cfg.device
         d_sym = DeviceBuffer(max(8, in0.nbytes), dev).upload(in0)
         d_hard = DeviceBuffer(max(8, n * bps), dev)
-        soft = bps == 2
+        soft = bps in (2, 4, 6)
         d_s0 = DeviceBuffer(max(8, n * bps * 4), dev) if soft else None
         d_s1 = DeviceBuffer(max(8, n * bps * 4), dev) if soft else None
         self._engine.demap(d_sym, n, bps, d_hard, d_s0, d_s1)
