@@ -34,7 +34,8 @@ typedef enum {
     OFDM_ERR_HIP = -2,          /* HIP runtime error (no device, launch failure, ...)              */
     OFDM_ERR_INDEX = -3,        /* the reference would raise IndexError (row >= num_ofdm_symb)     */
     OFDM_ERR_SHAPE = -4,        /* the reference would raise ValueError (reshape / assignment)     */
-    OFDM_ERR_NOMEM = -5
+    OFDM_ERR_NOMEM = -5,
+    OFDM_ERR_UNBOUND = -6       /* the reference would raise UnboundLocalError (SynchEstFOAndDSSS.py:392) */
 } ofdm_status;
 
 typedef enum { OFDM_MOD_BPSK = 1, OFDM_MOD_QPSK = 2, OFDM_MOD_16QAM = 4, OFDM_MOD_64QAM = 6 } ofdm_modulation;
@@ -195,7 +196,8 @@ typedef struct ofdm_fo_cfg {
     double snr;                /* self.SNR (:150), linear                                                      */
     const float* rotators;     /* host, [n_fo][nfft] complex64 interleaved: self.cfo (:192); copied             */
     int32_t device;
-    int32_t reserved;
+    int32_t dsss;              /* 0: SynchEstAndFO.  >= 1: SynchEstFOAndDSSS with spreading factor self.DSSS     */
+    const float* spread_code;  /* host, [dsss] complex64 interleaved: self.SC (SynchEstFOAndDSSS.py:253-262); copied */
 } ofdm_fo_cfg;
 
 typedef struct ofdm_fo_report {
@@ -215,6 +217,12 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
  * h_chan_freq[100][nfft], h_chan_time[100][nfft], h_synch_freq[100][S*Ks], h_data_freq[100][Kd], h_eq_gain[Ks]. */
 int ofdm_fo_get_state(ofdm_fo* h, double* h_tsr, float* h_chan_freq, float* h_chan_time, float* h_synch_freq,
                       float* h_data_freq, float* h_eq_gain);
+/* DSSS variant (cfg.dsss >= 1; SynchEstFOAndDSSS.py:28-413, grc/OFDMReceiver_SynchEstFOAndDSSS.block.yml): after the
+ * equaliser every row is despread -- est_data_freq_d[P][i] = mean_SF(est_data_freq[P][SF + i*DSSS] * conj(SC[SF])),
+ * i < floor(Kd/DSSS) (:391-399) -- and ofdm_fo_work emits the first corr_size despread rows on EVERY call (:405-407).
+ * OFDM_ERR_UNBOUND: row 0 of an earlier call fails the data guard before any row passed (:392).
+ * h_data_freq_d[100][floor(Kd/DSSS)] complex64 interleaved. */
+int ofdm_fo_get_despread(ofdm_fo* h, float* h_data_freq_d);
 
 /* ------------------------------------------------------------------------------------------ misc */
 /* Measurement aid for bench.py: mode 0 = float4 device copy of `bytes` (achievable HBM rate of this chip, same run);

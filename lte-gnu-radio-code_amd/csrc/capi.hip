@@ -166,6 +166,9 @@ struct ofdm_fo {
     cf* t_esf = nullptr;                 // [100][MM]
     cf* t_gain = nullptr;                // [100][Kd]
     cf* t_edf = nullptr;                 // [100][Kd]  est_data_freq
+    cf* d_code = nullptr;                // [dsss]     self.SC      (DSSS variant only)
+    cf* t_edfd = nullptr;                // [100][Kd/dsss] est_data_freq_d
+    int n_spread = 0;
     cf* s_eqg = nullptr;                 // [Ks]
     cf* s_ysc = nullptr;                 // [MM]
     float* d_trial_m = nullptr;          // [n_fo * TRIAL_WIN]
@@ -690,7 +693,7 @@ int ofdm_fo_destroy(ofdm_fo* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_tw, h->d_zc, h->d_rot, h->d_in, h->t_tsr, h->t_H, h->t_htime, h->t_esf, h->t_gain,
-                    h->t_edf, h->s_eqg, h->s_ysc, h->d_trial_m, h->d_trial_d};
+                    h->t_edf, h->d_code, h->t_edfd, h->s_eqg, h->s_ysc, h->d_trial_m, h->d_trial_d};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -711,12 +714,16 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     if (c->num_ofdm_symb < 1) return fail(OFDM_ERR_INVALID, "num_ofdm_symb must be >= 1");
     if (c->n_fo < 1 || !c->rotators) return fail(OFDM_ERR_INVALID, "fo_range must hold at least one candidate");
     if (!(c->snr > 0.0)) return fail(OFDM_ERR_INVALID, "snr must be > 0 (linear)");
+    if (c->dsss < 0 || c->dsss > c->num_data_bins || (c->dsss > 0 && !c->spread_code))
+        return fail(OFDM_ERR_INVALID, "dsss=%d must be 0 or in [1, num_data_bins] with a spreading code", c->dsss);
 
     HIP_TRY(hipSetDevice(c->device));
     ofdm_fo* h = new (std::nothrow) ofdm_fo();
     if (!h) return fail(OFDM_ERR_NOMEM, "out of host memory");
     h->cfg = *c;
-    h->cfg.rotators = nullptr;            // the caller's table is copied below, never kept
+    h->cfg.rotators = nullptr;            // the caller's tables are copied below, never kept
+    h->cfg.spread_code = nullptr;
+    h->n_spread = c->dsss > 0 ? c->num_data_bins / c->dsss : 0;
     ofdm_rx_cfg rc_cfg{};
     rc_cfg.num_ofdm_symb = c->num_ofdm_symb;
     rc_cfg.nfft = c->nfft;
@@ -749,6 +756,13 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_edf, R * Kd);
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_eqg, size_t(Ks));
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_ysc, size_t(MM));
+    if (rc == OFDM_OK && c->dsss > 0) rc = dev_alloc(&h->d_code, size_t(c->dsss));
+    if (rc == OFDM_OK && c->dsss > 0) rc = dev_alloc(&h->t_edfd, R * size_t(h->n_spread));
+    if (rc == OFDM_OK && c->dsss > 0) {
+        bool ok = hipMemcpy(h->d_code, c->spread_code, size_t(c->dsss) * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemset(h->t_edfd, 0, R * size_t(h->n_spread) * sizeof(cf)) == hipSuccess;
+        if (!ok) rc = fail(OFDM_ERR_HIP, "spreading-code upload failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_m, size_t(c->n_fo) * ofdm_fo::TRIAL_WIN);
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_d, size_t(c->n_fo) * ofdm_fo::TRIAL_WIN);
     if (rc == OFDM_OK) {
@@ -803,7 +817,7 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
         rep->count = h->count;
         rep->dmax_tmp_ind = h->dmax_tmp_ind;
         rep->trials_run = trials_run;
-        rep->n_data_items = int64_t(h->cfg.num_ofdm_symb / (d.S + d.D)) * Kd;
+        rep->n_data_items = int64_t(h->cfg.num_ofdm_symb / (d.S + d.D)) * (h->cfg.dsss > 0 ? h->n_spread : Kd);
     };
 
     // ---------------- Loop A: every valid trial, every candidate; NO break (FO:248-329)
@@ -890,6 +904,9 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
             if (ptr + N - 1 <= n_in && ptr + N > n_in)                                       // :334 passes, slice has N-1 items
                 return fail(OFDM_ERR_SHAPE, "data window of sync %d is one sample short (the reference raises ValueError)", r);
         }
+        if (h->cfg.dsss > 0 && !(int64_t(h->tsr[0][0]) + int64_t(S) * L + N - 1 <= n_in))   // DS:362 fails for row 0 ...
+            return fail(OFDM_ERR_UNBOUND, "row 0 fails the data guard before any row passed (the reference raises UnboundLocalError, "
+                                          "SynchEstFOAndDSSS.py:392)");                       // ... rows >= 1 of this call always pass
         if (h->dmax_tmp_ind < 0)
             return fail(OFDM_ERR_INVALID, "no trial has ever been evaluated: dmax_tmp_ind is undefined (the reference raises NameError)");
         DemodArgs da{};
@@ -911,6 +928,8 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
         da.zero_skipped = 0;
         da.rot = h->d_rot + size_t(h->dmax_tmp_ind) * N;                                     // :339
         HIP_TRY(launch_rx_demod(d, da, s));
+        if (h->cfg.dsss > 0)                                                                 // DS:391-399
+            HIP_TRY(launch_despread(h->t_edf, Kd, h->d_code, h->cfg.dsss, h->n_spread, n_sync, h->t_edfd, s));
     }
 
     // ---------------- output (:362-367)
@@ -918,7 +937,13 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
     if (corr_size > OFDM_FO_MAX_SYNC)
         return fail(OFDM_ERR_SHAPE, "corr_size=%lld exceeds the %d est_data_freq rows (the reference raises ValueError)",
                     (long long)corr_size, OFDM_FO_MAX_SYNC);
-    if (h->count > 0) {
+    if (h->cfg.dsss > 0) {                                                                   // DS:403-407: every call
+        if (corr_size * h->n_spread > n_out)
+            return fail(OFDM_ERR_SHAPE, "output buffer holds %lld items, need %lld (the reference raises ValueError)",
+                        (long long)n_out, (long long)(corr_size * h->n_spread));
+        if (corr_size * h->n_spread > 0)
+            HIP_TRY(hipMemcpyAsync(h_out, h->t_edfd, size_t(corr_size) * h->n_spread * sizeof(cf), hipMemcpyDeviceToHost, s));
+    } else if (h->count > 0) {
         if (corr_size * Kd > n_out)
             return fail(OFDM_ERR_SHAPE, "output buffer holds %lld items, need %lld (the reference raises ValueError)",
                         (long long)n_out, (long long)(corr_size * Kd));
@@ -944,6 +969,15 @@ int ofdm_fo_get_state(ofdm_fo* h, double* h_tsr, float* h_chan_freq, float* h_ch
     if (h_synch_freq) HIP_TRY(hipMemcpy(h_synch_freq, h->t_esf, R * d.MM * sizeof(cf), hipMemcpyDeviceToHost));
     if (h_data_freq) HIP_TRY(hipMemcpy(h_data_freq, h->t_edf, R * d.Kd * sizeof(cf), hipMemcpyDeviceToHost));
     if (h_eq_gain) HIP_TRY(hipMemcpy(h_eq_gain, h->s_eqg, size_t(d.Ks) * sizeof(cf), hipMemcpyDeviceToHost));
+    return OFDM_OK;
+}
+
+int ofdm_fo_get_despread(ofdm_fo* h, float* h_data_freq_d) {
+    if (!h || !h_data_freq_d) return fail(OFDM_ERR_INVALID, "ofdm_fo_get_despread: null argument");
+    if (h->cfg.dsss <= 0) return fail(OFDM_ERR_INVALID, "handle was not created with dsss >= 1");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h_data_freq_d, h->t_edfd, size_t(OFDM_FO_MAX_SYNC) * h->n_spread * sizeof(cf), hipMemcpyDeviceToHost));
     return OFDM_OK;
 }
 

@@ -96,6 +96,8 @@ struct ChanArgs {
 hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s);
 hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s);
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s);
+// out[row][i] = mean_SF( in[row][SF + i*dsss] * conj(code[SF]) ), i < n_spread  (SynchEstFOAndDSSS.py:391-399)
+hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out, hipStream_t s);
 hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s);
 hipError_t launch_channel(const ChanArgs& a, hipStream_t s);
 size_t rx_lds_bytes(int nfft);

@@ -447,6 +447,17 @@ __global__ void __launch_bounds__(256) demap_soft_qam_kernel(DemapArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ DSSS despreading
+__global__ void despread_kernel(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (i >= n_spread || row >= rows) return;
+    const cf* x = in + int64_t(row) * in_row_stride + int64_t(i) * dsss;
+    cf acc = cf{0.f, 0.f};
+    for (int sf = 0; sf < dsss; ++sf) acc = acc + cmulc(x[sf], code[sf]);              // x * conj(SC[sf])  (:395)
+    out[int64_t(row) * n_spread + i] = cscale(acc, 1.f / float(dsss));                  // np.average        (:396)
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 template <int N>
 static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
@@ -492,6 +503,13 @@ size_t rx_lds_bytes(int nfft) {
     }
 #undef CALL
     return 0;
+}
+
+hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out, hipStream_t s) {
+    if (rows <= 0 || n_spread <= 0) return hipSuccess;
+    hipLaunchKernelGGL(despread_kernel, dim3(unsigned((n_spread + 63) / 64), unsigned(rows)), dim3(64), 0, s, in, in_row_stride, code,
+                       dsss, n_spread, rows, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {

@@ -50,6 +50,11 @@ BLOCKS = [
          params=[("case", "Case Number", "int"), ("fo_range", "F Offset Range", "raw"), ("directory_name", "Directory Path", "string"),
                  ("file_name_cest", "Var: Chan Est -- File Name", "string"), ("diagnostics", "Diagnostics", "int")],
          make_args=["case", "fo_range", "directory_name", "file_name_cest", "diagnostics"], inputs=CPLX_IN, outputs=CPLX_IN),
+    dict(id="OFDMReceiver_SynchEstFOAndDSSS", label="SynchEstFOAndDSSS (MI355X)", category="[OFDMReceiver]", module="OFDMReceiver",
+         cls="SynchEstFOAndDSSS",
+         params=[("case", "Case Number", "int"), ("fo_range", "F Offset Range", "raw"), ("directory_name", "Directory Path", "string"),
+                 ("file_name_cest", "Var: Chan Est -- File Name", "string"), ("diagnostics", "Diagnostics", "int")],
+         make_args=["case", "fo_range", "directory_name", "file_name_cest", "diagnostics"], inputs=CPLX_IN, outputs=CPLX_IN),
 ]
 
 

@@ -17,6 +17,7 @@ OFDM_ERR_HIP = -2
 OFDM_ERR_INDEX = -3
 OFDM_ERR_SHAPE = -4
 OFDM_ERR_NOMEM = -5
+OFDM_ERR_UNBOUND = -6
 
 COMPAT_UTSA = 0
 COMPAT_RXOFDM = 1
@@ -54,7 +55,7 @@ class FoCfg(C.Structure):
     _fields_ = [("num_ofdm_symb", C.c_int32), ("nfft", C.c_int32), ("cp_len", C.c_int32),
                 ("num_synch_bins", C.c_int32), ("synch_S", C.c_int32), ("synch_D", C.c_int32),
                 ("num_data_bins", C.c_int32), ("n_fo", C.c_int32), ("snr", C.c_double),
-                ("rotators", C.c_void_p), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("rotators", C.c_void_p), ("device", C.c_int32), ("dsss", C.c_int32), ("spread_code", C.c_void_p)]
 
 
 class FoReport(C.Structure):
@@ -93,6 +94,7 @@ PROTOTYPES = {
     "ofdm_fo_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_fo_work": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(FoReport)]),
     "ofdm_fo_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofdm_fo_get_despread": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ofdm_tx_create": (C.c_int, [C.POINTER(TxCfg), C.POINTER(C.c_void_p)]),
     "ofdm_tx_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_tx_modulate_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
@@ -145,6 +147,8 @@ def check(rc: int):
         raise ValueError(msg)
     if rc == OFDM_ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == OFDM_ERR_UNBOUND:
+        raise UnboundLocalError(msg)
     raise OfdmError(msg)
 
 

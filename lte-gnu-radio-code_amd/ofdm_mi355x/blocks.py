@@ -156,14 +156,17 @@ class SynchEstAndFO(sync_block):
     evidently intended rotators exp(j 2 pi fo n / fs) (no reference output exists for it).
     """
 
+    _CASES = _FO_CASES
+    _NAME = "SynchEstAndFO"
+
     def __init__(self, case, fo_range, directory_name, file_name_cest, diagnostics, py2_rotators=True):
-        sync_block.__init__(self, name="SynchEstAndFO", in_sig=[np.complex64], out_sig=[np.complex64])
+        sync_block.__init__(self, name=self._NAME, in_sig=[np.complex64], out_sig=[np.complex64])
         self.case = case
-        if case not in _FO_CASES:
+        if case not in self._CASES:
             # :136 prints "Error: Case Out of Bounds" and then fails on the first missing attribute
             print("Error: Case Out of Bounds")
-            raise AttributeError("'SynchEstAndFO' object has no attribute 'num_synch_bins'")
-        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = _FO_CASES[case]
+            raise AttributeError("'%s' object has no attribute 'num_synch_bins'" % self._NAME)
+        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = self._CASES[case][:5]
         self.synch_dat = list(sd)
         self.cp_len = self.nfft // 4
         self.num_synch_bins = self.nfft - 2
@@ -188,8 +191,11 @@ class SynchEstAndFO(sync_block):
         self.file_name_cest = file_name_cest
         self.diagnostics = diagnostics
         self._engine = FoEngine(self.num_ofdm_symb, self.nfft, self.cp_len, self.num_synch_bins, self.synch_dat,
-                                self.num_data_bins, self.SNR, self.cfo, device=_device())
+                                self.num_data_bins, self.SNR, self.cfo, device=_device(), spread_code=self._spread_code())
         self._n_sync = 0
+
+    def _spread_code(self):
+        return None
 
     def _state(self, key):
         return self._engine.state()[key]
@@ -237,6 +243,36 @@ class SynchEstAndFO(sync_block):
             with open(str(self.directory_name) + str(self.file_name_cest) + date_time + '.pckl', 'wb') as f:
                 pickle.dump(chan_est_tim, f, protocol=2)
         return n
+
+
+# SynchEstFOAndDSSS's case table (LEGACY/gr-ofdm-rx/python/SynchEstFOAndDSSS.py:37-157): ... + DSSS spreading factor
+_DSSS_CASES = {
+    0: (48, 960000, 64, [2, 1], 12, 1), 1: (48, 960000, 64, [3, 1], 36, 6), 2: (45, 960000, 64, [4, 1], 48, 6),
+    3: (45, 960000, 64, [4, 1], 48, 12), 4: (24, 1920000, 128, [3, 1], 32, 8), 5: (20, 1920000, 128, [4, 1], 84, 12),
+    6: (20, 1920000, 128, [4, 1], 96, 16), 7: (24, 1920000, 128, [5, 1], 120, 24), 8: (12, 3840000, 256, [3, 1], 168, 12),
+    9: (10, 3840000, 256, [4, 1], 192, 16), 10: (10, 3840000, 256, [4, 1], 240, 24),
+}
+
+
+class SynchEstFOAndDSSS(SynchEstAndFO):
+    """OFDMReceiver.SynchEstFOAndDSSS(case, fo_range, directory_name, file_name_cest, diagnostics) -- SynchEstAndFO with its
+    own numerology table, followed by despreading of every equalised data symbol over groups of DSSS consecutive bins
+    (SynchEstFOAndDSSS.py:391-399).  The despread rows are emitted on every call (the count gate is commented out, :405-407)."""
+
+    _CASES = _DSSS_CASES
+    _NAME = "SynchEstFOAndDSSS"
+
+    def _spread_code(self):
+        self.DSSS = self._CASES[self.case][5]
+        dd = self.DSSS
+        t0 = np.arange(dd, dtype=np.float64)
+        xx = t0 * t0 if dd % 2 == 0 else t0 * (t0 + 1)                           # :253-259
+        self.SC = np.exp((-1j * (2 * np.pi / dd) * self.p / 2.0) * xx)          # :261-262
+        return self.SC
+
+    @property
+    def est_data_freq_d(self):
+        return self._engine.despread().astype(complex)
 
 
 def _load_iq_file(path: str) -> np.ndarray:

@@ -169,17 +169,23 @@ class FoEngine:
     """CFO-search receiver handle (reference: LEGACY/gr-ofdm-rx/python/SynchEstAndFO.py): trial x candidate sync table,
     up to 100 syncs per call, one equalised data symbol per sync."""
 
-    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, rotators, device=0):
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, rotators, device=0,
+                 spread_code=None):
+        """spread_code: None = SynchEstAndFO; a complex sequence of length DSSS = SynchEstFOAndDSSS (despread output)."""
         self.lib = _lib.load()
         rot = np.ascontiguousarray(rotators, dtype=np.complex64)
         if rot.ndim != 2 or rot.shape[1] != int(nfft) or rot.shape[0] < 1:
             raise ValueError("rotators must be [len(fo_range) >= 1][nfft]")
+        code = None if spread_code is None else np.ascontiguousarray(spread_code, dtype=np.complex64).ravel()
+        self.dsss = 0 if code is None else int(code.size)
+        self.n_spread = int(num_data_bins) // self.dsss if self.dsss else 0
         self.cfg = _lib.FoCfg(int(num_ofdm_symb), int(nfft), int(cp_len), int(num_synch_bins), int(synch_dat[0]),
                               int(synch_dat[1]), int(num_data_bins), int(rot.shape[0]), float(snr),
-                              rot.ctypes.data, int(device), 0)
+                              rot.ctypes.data, int(device), self.dsss, None if code is None else code.ctypes.data)
         h = C.c_void_p()
         check(self.lib.ofdm_fo_create(C.byref(self.cfg), C.byref(h)))
-        self.cfg.rotators = None          # the library copied the table
+        self.cfg.rotators = None          # the library copied the tables
+        self.cfg.spread_code = None
         self._h = h
         self.report = _lib.FoReport()
 
@@ -206,6 +212,11 @@ class FoEngine:
         eqg = np.zeros(c.num_synch_bins, np.complex64)
         check(self.lib.ofdm_fo_get_state(self._h, ptr(tsr), ptr(H), ptr(ht), ptr(esf), ptr(edf), ptr(eqg)))
         return dict(time_synch_ref=tsr, chan_freq=H, chan_time=ht, synch_freq=esf, data_freq=edf, eq_gain=eqg)
+
+    def despread(self):
+        out = np.zeros((_lib.FO_MAX_SYNC, self.n_spread), np.complex64)
+        check(self.lib.ofdm_fo_get_despread(self._h, ptr(out)))
+        return out
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -200,7 +200,7 @@ def soft_demap_qam(z: np.ndarray, modulation: str):
 
 def tx_grid(bits: np.ndarray, nfft: int, num_synch_bins: int, num_data_bins: int,
             n_sym: int, synch_dat=(1, 3), modulation: str = "QPSK", zc_root: int = 23, zc_segments: bool = False,
-            zc_parity_of_bins: bool = False) -> np.ndarray:
+            zc_parity_of_bins: bool = False, data_symbols=None) -> np.ndarray:
     """Resource grid (n_sym, nfft): ZC on sync symbols, mapped data on data symbols.
 
     TX:135-183.  ``synch_state`` never advances (TX:146) so every sync symbol carries
@@ -225,8 +225,11 @@ def tx_grid(bits: np.ndarray, nfft: int, num_synch_bins: int, num_data_bins: int
             seg = (s % (S + D)) if zc_segments else 0
             grid[s, sb] = zc[seg * num_synch_bins:(seg + 1) * num_synch_bins]
         else:
-            chunk = bits[nd * num_data_bins * bps:(nd + 1) * num_data_bins * bps]
-            grid[s, db] = map_bits(chunk, modulation)
+            if data_symbols is not None:      # pre-mapped bin values [n_data][Kd] (e.g. DSSS-spread symbols)
+                grid[s, db] = np.asarray(data_symbols)[nd]
+            else:
+                chunk = bits[nd * num_data_bins * bps:(nd + 1) * num_data_bins * bps]
+                grid[s, db] = map_bits(chunk, modulation)
             nd += 1
     return grid
 
@@ -248,11 +251,22 @@ def tx_symbol_synth(grid: np.ndarray, cp_len: int) -> np.ndarray:
 
 
 def tx_modulate(bits, nfft, cp_len, num_synch_bins, num_data_bins, n_sym,
-                synch_dat=(1, 3), modulation="QPSK", zc_root=23, zc_segments=False, zc_parity_of_bins=False) -> np.ndarray:
+                synch_dat=(1, 3), modulation="QPSK", zc_root=23, zc_segments=False, zc_parity_of_bins=False,
+                data_symbols=None) -> np.ndarray:
     """bits -> time-domain IQ (a1+a2+a3)."""
     return tx_symbol_synth(
         tx_grid(bits, nfft, num_synch_bins, num_data_bins, n_sym, synch_dat, modulation, zc_root, zc_segments,
-                zc_parity_of_bins), cp_len)
+                zc_parity_of_bins, data_symbols), cp_len)
+
+
+def dsss_spread(symbols: np.ndarray, dsss: int, num_data_bins: int) -> np.ndarray:
+    """Transmit-side counterpart of DS:391-399 (the reference has no transmitter for it): each symbol of a row occupies DSSS
+    consecutive listed bins, multiplied by the spreading code; bins past floor(Kd/DSSS)*DSSS stay empty."""
+    symbols = np.atleast_2d(np.asarray(symbols))
+    n = num_data_bins // dsss
+    out = np.zeros((symbols.shape[0], num_data_bins), dtype=np.complex128)
+    out[:, :n * dsss] = (symbols[:, :n, None] * spreading_code(dsss)[None, None, :]).reshape(symbols.shape[0], n * dsss)
+    return out
 
 
 REF_TAPS = np.array([0.3977, 0.7954 - 0.3977j, -0.1988, 0.0994, -0.0398])  # TX:64
@@ -542,11 +556,13 @@ class FoOracle:
 
     MAX_CORR = 100
 
+    CASES = FO_CASES
+
     def __init__(self, case, fo_range, py2_rotators=True):
         """py2_rotators=True reproduces the only executable semantics of the file: under Python 2, `(1/self.fs)` in FO:192
         is an INTEGER division (fs is an int) = 0, so every carrier-offset rotator is exp(0) = 1 and the search is a no-op
         (all candidates tie, index 0 wins).  py2_rotators=False uses 1.0/fs, the evidently intended rotators (unpinned)."""
-        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = FO_CASES[case]
+        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = self.CASES[case][:5]
         self.synch_dat = [int(sd[0]), int(sd[1])]
         self.cp_len = self.nfft // 4                                         # FO:39 (py2 int division)
         self.num_synch_bins = self.nfft - 2
@@ -581,6 +597,17 @@ class FoOracle:
 
     def work(self, in0, out):
         in0 = np.asarray(in0)
+        self._loop_a(in0)
+        self._loop_b(in0)
+        corr_size = self.num_ofdm_symb // sum(self.synch_dat)                # FO:362 (py2 int division)
+        data_out = np.reshape(self.est_data_freq[0:corr_size], (1, corr_size * self.num_data_bins))   # FO:364
+        if self.count > 0:
+            out[0:data_out.shape[1]] = data_out[0]                           # FO:366-367
+        self.count += 1
+        self.cor_obs = 0                                                     # FO:369
+        return len(out)
+
+    def _loop_a(self, in0):
         n_in = len(in0)
         S, N, L, cp = self.M[0], self.nfft, self.rx_b_len, self.cp_len
         zc_c = np.conj(self.zadoff_chu)
@@ -615,20 +642,79 @@ class FoOracle:
                         self.est_chan_time[self.cor_obs] = np.fft.ifft(chan_est1, N)          # FO:313,323
                         self.eq_gain = np.conj(chan_est) / (1.0 / self.SNR + chan_est * np.conj(chan_est))   # FO:324-327
                         self.est_synch_freq[self.cor_obs] = np.tile(self.eq_gain, S) * data_recov           # FO:328-329
+    def _demod_row(self, in0, P):
+        """One equalised data symbol of sync P (FO:335-358); None when the guard FO:334 fails."""
+        S, N, L = self.M[0], self.nfft, self.rx_b_len
+        if not (self.time_synch_ref[P][0] + S * L + N - 1 <= len(in0)):      # FO:334
+            return None
+        data_ptr = int(self.time_synch_ref[P][0] + S * L)                    # FO:335
+        x = in0[data_ptr: data_ptr + N] * self.cfo[self.dmax_tmp_ind]        # FO:338-339 (ValueError if the slice is short)
+        t_vec = np.fft.fft(x, N)                                             # FO:340
+        f0 = t_vec[self.bins_used_P]
+        f0 = f0 * np.sqrt(len(f0) / np.dot(f0, np.conj(f0)))                 # FO:343-345
+        f0 = f0 * np.exp((1j * (2 * np.pi / N)) * self.time_synch_ref[P][1] * self.bins_used_P)   # FO:347-350
+        hd = self.est_chan_freq_P[P][self.bins_used_P]                       # FO:352
+        return np.conj(hd) / (1.0 / self.SNR + hd * np.conj(hd)) * f0        # FO:354-358
+
+    def _loop_b(self, in0):
         for P in range(self.cor_obs + 1):                                    # FO:332
-            if self.time_synch_ref[P][0] + S * L + N - 1 <= n_in:            # FO:334
-                data_ptr = int(self.time_synch_ref[P][0] + S * L)            # FO:335
-                x = in0[data_ptr: data_ptr + N] * self.cfo[self.dmax_tmp_ind]    # FO:338-339 (ValueError if the slice is short)
-                t_vec = np.fft.fft(x, N)                                     # FO:340
-                f0 = t_vec[self.bins_used_P]
-                f0 = f0 * np.sqrt(len(f0) / np.dot(f0, np.conj(f0)))         # FO:343-345
-                f0 = f0 * np.exp((1j * (2 * np.pi / N)) * self.time_synch_ref[P][1] * self.bins_used_P)   # FO:347-350
-                hd = self.est_chan_freq_P[P][self.bins_used_P]               # FO:352
-                self.est_data_freq[P] = np.conj(hd) / (1.0 / self.SNR + hd * np.conj(hd)) * f0   # FO:354-358
-        corr_size = self.num_ofdm_symb // sum(self.synch_dat)                # FO:362 (py2 int division)
-        data_out = np.reshape(self.est_data_freq[0:corr_size], (1, corr_size * self.num_data_bins))   # FO:364
-        if self.count > 0:
-            out[0:data_out.shape[1]] = data_out[0]                           # FO:366-367
+            row = self._demod_row(in0, P)
+            if row is not None:
+                self.est_data_freq[P] = row
+
+
+# numerology of G/LEGACY/gr-ofdm-rx/python/SynchEstFOAndDSSS.py:37-157 (DS = that file)
+# case -> (num_ofdm_symb, fs, nfft, synch_dat, num_data_bins, DSSS); cp_len = nfft/4, num_synch_bins = nfft-2, SNR = 1e8
+DSSS_CASES = {
+    0: (48, 960000, 64, (2, 1), 12, 1), 1: (48, 960000, 64, (3, 1), 36, 6), 2: (45, 960000, 64, (4, 1), 48, 6),
+    3: (45, 960000, 64, (4, 1), 48, 12), 4: (24, 1920000, 128, (3, 1), 32, 8), 5: (20, 1920000, 128, (4, 1), 84, 12),
+    6: (20, 1920000, 128, (4, 1), 96, 16), 7: (24, 1920000, 128, (5, 1), 120, 24), 8: (12, 3840000, 256, (3, 1), 168, 12),
+    9: (10, 3840000, 256, (4, 1), 192, 16), 10: (10, 3840000, 256, (4, 1), 240, 24),
+}
+
+
+def spreading_code(dsss: int, p: int = 37) -> np.ndarray:
+    """ZC-form spreading sequence of length DSSS (DS:253-262)."""
+    t0 = np.arange(dsss, dtype=np.float64)
+    xx = t0 * t0 if dsss % 2 == 0 else t0 * (t0 + 1)
+    return np.exp((-1j * (2 * np.pi / dsss) * p / 2.0) * xx)
+
+
+class FoDsssOracle(FoOracle):
+    """SynchEstFOAndDSSS (DS:28-413) = SynchEstAndFO with its own case table plus: every equalised data symbol is despread
+    over groups of DSSS consecutive listed bins with conj(SC) and averaged (DS:391-399); the output is the despread rows and
+    is written on EVERY call (the count gate is commented out, DS:405-407).  Kept literally: the statement DS:392 re-assigns
+    est_data_freq[P] from the loop's locals outside the guard, so a row whose guard fails before any row passed raises
+    UnboundLocalError (only row 0 of an earlier call can do that)."""
+
+    CASES = DSSS_CASES
+
+    def __init__(self, case, fo_range, py2_rotators=True):
+        FoOracle.__init__(self, case, fo_range, py2_rotators)
+        self.DSSS = self.CASES[case][5]
+        self.SC = spreading_code(self.DSSS, self.p)
+        self.est_data_freq_d = np.zeros((self.MAX_CORR, int(self.num_data_bins // self.DSSS)), dtype=complex)   # DS:243
+
+    def _loop_b(self, in0):
+        n_spread = int(len(self.bins_used_P) // self.DSSS)                   # DS:358
+        last = None
+        for P in range(self.cor_obs + 1):                                    # DS:360
+            row = self._demod_row(in0, P)
+            if row is not None:
+                last = row
+            if last is None:
+                raise UnboundLocalError("local variable 'data_recov_z' referenced before assignment")   # DS:392
+            self.est_data_freq[P] = last                                     # DS:392
+            grp = self.est_data_freq[P][:n_spread * self.DSSS].reshape(n_spread, self.DSSS)
+            self.est_data_freq_d[P] = np.mean(grp * np.conj(self.SC)[None, :], axis=1)          # DS:393-397
+
+    def work(self, in0, out):
+        in0 = np.asarray(in0)
+        self._loop_a(in0)
+        self._loop_b(in0)
+        corr_size = self.num_ofdm_symb // sum(self.synch_dat)                # DS:401
+        data_out = np.reshape(self.est_data_freq_d[0:corr_size], (1, corr_size * self.est_data_freq_d.shape[1]))
+        out[0:data_out.shape[1]] = data_out[0]                               # DS:407 (no count gate)
         self.count += 1
-        self.cor_obs = 0                                                     # FO:369
+        self.cor_obs = 0
         return len(out)

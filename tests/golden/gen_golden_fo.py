@@ -54,11 +54,11 @@ def _py2div(a, b):
     return a / b
 
 
-def load_reference_class():
-    tree = ast.fix_missing_locations(_Py2Div().visit(ast.parse(open(PATH).read())))
-    ns = {"_py2div": _py2div, "__name__": "ref_synch_est_and_fo"}
-    exec(compile(tree, PATH, "exec"), ns)
-    return ns["SynchEstAndFO"]
+def load_reference_class(path=PATH, name="SynchEstAndFO"):
+    tree = ast.fix_missing_locations(_Py2Div().visit(ast.parse(open(path).read())))
+    ns = {"_py2div": _py2div, "__name__": "ref_" + name}
+    exec(compile(tree, path, "exec"), ns)
+    return ns[name]
 
 
 CASES = [

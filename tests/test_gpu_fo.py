@@ -157,3 +157,53 @@ def test_fo_block_quiet_buffer_keeps_state():
         assert not blk.time_synch_ref.any() and not o.time_synch_ref.any()
         assert np.allclose(blk.est_data_freq, o.est_data_freq, atol=1e-6)
         assert np.allclose(rb, ro, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ DSSS variant
+def _dsss_block(case, fo_range, **kw):
+    import OFDMReceiver
+    return OFDMReceiver.SynchEstFOAndDSSS(case, list(fo_range), "/tmp/ofdm_fo_", "cest", 0, **kw)
+
+
+@pytest.mark.parametrize("tag", ["d1", "d3", "d4", "d8", "d10"])
+def test_dsss_block_on_reference_runs(golden, tag):
+    """OFDMReceiver.SynchEstFOAndDSSS vs recorded runs of the reference block (tests/golden/ref_dsss.npz)."""
+    g = golden("ref_dsss.npz")
+    blk = _dsss_block(int(g[tag + "_meta"][0]), g[tag + "_fo_range"])
+    iq = g[tag + "_iq"]
+    for call in (1, 2):
+        out = np.zeros(len(iq), np.complex64)
+        assert blk.work([iq], [out]) == len(iq)
+        k = "%s_call%d_" % (tag, call)
+        _check_table(blk.time_synch_ref, g[k + "tsr"])
+        assert blk.dmax_tmp_ind == int(g[k + "fo_idx"][0])
+        assert relerr(blk.est_chan_freq_P, g[k + "H"]) < TOL
+        assert relerr(blk.est_data_freq, g[k + "edf"]) < TOL
+        assert relerr(blk.est_data_freq_d, g[k + "edfd"]) < TOL
+        assert out.any() and relerr(out, g[k + "out"]) < TOL            # emitted on every call
+        assert blk.count == call and blk.cor_obs == 0
+    n_sync = int(np.count_nonzero(blk.time_synch_ref[:, 2]))
+    n_spread = blk.est_data_freq_d.shape[1]
+    got = orc.demap_hard(blk.est_data_freq_d[:n_sync].ravel(), "QPSK")
+    assert np.array_equal(got, g[tag + "_bits"][:n_sync * n_spread * 2])
+
+
+def test_dsss_block_unbound_local_like_the_reference():
+    o = orc.FoDsssOracle(1, [0.0])
+    blk = _dsss_block(1, [0.0])
+    n_symb, fs, N, sd, Kd, dsss = orc.DSSS_CASES[1]
+    rng = np.random.default_rng(0)
+    sym = orc.map_bits(rng.integers(0, 2, 12 * (Kd // dsss) * 2), "QPSK").reshape(12, Kd // dsss)
+    iq = orc.tx_modulate(None, N, N // 4, N - 2, Kd, n_symb, synch_dat=sd, zc_root=37, zc_segments=True,
+                         zc_parity_of_bins=True, data_symbols=orc.dsss_spread(sym, dsss, Kd)).astype(np.complex64)
+    ro, rb = np.zeros(len(iq), np.complex64), np.zeros(len(iq), np.complex64)
+    o.work(iq, ro)
+    blk.work([iq], [rb])
+    assert relerr(rb, ro) < TOL
+    short = iq[:int(o.time_synch_ref[0][0]) + sd[0] * (N + N // 4) + N - 2]
+    with pytest.raises(UnboundLocalError):
+        o.work(short, np.zeros(len(short), np.complex64))
+    with pytest.raises(UnboundLocalError):
+        blk.work([short], [np.zeros(len(short), np.complex64)])
+    with pytest.raises(AttributeError):
+        _dsss_block(11, [0.0])
