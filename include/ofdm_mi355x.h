@@ -194,7 +194,9 @@ typedef struct ofdm_fo_cfg {
     int32_t num_data_bins;
     int32_t n_fo;              /* len(fo_range) >= 1                                                           */
     double snr;                /* self.SNR (:150), linear                                                      */
-    const float* rotators;     /* host, [n_fo][nfft] complex64 interleaved: self.cfo (:192); copied             */
+    const float* rotators;     /* host, [n_fo][nfft] complex64 interleaved: self.cfo (:192); copied.  NULL with
+                                * n_fo == 1: no rotation at all = work() of gr-RXOFDM's synch_and_chan_est
+                                * (gr-RXOFDM/python/synch_and_chan_est.py:136-266), short data slices zero-padded (:228-230) */
     int32_t device;
     int32_t dsss;              /* 0: SynchEstAndFO.  >= 1: SynchEstFOAndDSSS with spreading factor self.DSSS     */
     const float* spread_code;  /* host, [dsss] complex64 interleaved: self.SC (SynchEstFOAndDSSS.py:253-262); copied */

@@ -712,7 +712,8 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
         return fail(OFDM_ERR_INVALID, "num_data_bins=%d must be even and in [2, nfft]", c->num_data_bins);
     if (c->synch_S < 1 || c->synch_D < 1) return fail(OFDM_ERR_INVALID, "synch_dat must be [>=1, >=1]");
     if (c->num_ofdm_symb < 1) return fail(OFDM_ERR_INVALID, "num_ofdm_symb must be >= 1");
-    if (c->n_fo < 1 || !c->rotators) return fail(OFDM_ERR_INVALID, "fo_range must hold at least one candidate");
+    if (c->n_fo < 1 || (!c->rotators && c->n_fo != 1))
+        return fail(OFDM_ERR_INVALID, "fo_range must hold at least one candidate (rotators may be NULL only with n_fo == 1)");
     if (!(c->snr > 0.0)) return fail(OFDM_ERR_INVALID, "snr must be > 0 (linear)");
     if (c->dsss < 0 || c->dsss > c->num_data_bins || (c->dsss > 0 && !c->spread_code))
         return fail(OFDM_ERR_INVALID, "dsss=%d must be 0 or in [1, num_data_bins] with a spreading code", c->dsss);
@@ -747,7 +748,7 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     auto zc = make_zc(MM, root, Ks);                                  // FO:168-176: parity of num_synch_bins
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM));
-    if (rc == OFDM_OK) rc = dev_alloc(&h->d_rot, size_t(c->n_fo) * N);
+    if (rc == OFDM_OK && c->rotators) rc = dev_alloc(&h->d_rot, size_t(c->n_fo) * N);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_tsr, R * 4);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_H, R * N);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_htime, R * N);
@@ -768,7 +769,8 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     if (rc == OFDM_OK) {
         bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemcpy(h->d_rot, c->rotators, size_t(c->n_fo) * N * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  (!c->rotators ||
+                   hipMemcpy(h->d_rot, c->rotators, size_t(c->n_fo) * N * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess) &&
                   hipMemset(h->t_tsr, 0, R * 4 * sizeof(int)) == hipSuccess &&
                   hipMemset(h->t_H, 0, R * N * sizeof(cf)) == hipSuccess &&
                   hipMemset(h->t_htime, 0, R * N * sizeof(cf)) == hipSuccess &&
@@ -879,7 +881,7 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
                 fa.p_begin = int(P);
                 fa.p_count = 1;
                 fa.force_accept = 1;
-                fa.rot = h->d_rot + size_t(n_fo - 1) * N;
+                fa.rot = h->d_rot ? h->d_rot + size_t(n_fo - 1) * N : nullptr;
                 fa.n_rot = 1;
                 fa.force_dhat_p1 = dmax_ind + 1;
                 fa.tsr = h->t_tsr + size_t(row) * 4;
@@ -901,13 +903,13 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
     if (n_sync > 0) {
         for (int r = 0; r < n_sync; ++r) {
             const int64_t ptr = int64_t(h->tsr[r][0]) + int64_t(S) * L;                      // :335
-            if (ptr + N - 1 <= n_in && ptr + N > n_in)                                       // :334 passes, slice has N-1 items
+            if (h->d_rot && ptr + N - 1 <= n_in && ptr + N > n_in)                           // :334 passes, slice has N-1 items
                 return fail(OFDM_ERR_SHAPE, "data window of sync %d is one sample short (the reference raises ValueError)", r);
         }
         if (h->cfg.dsss > 0 && !(int64_t(h->tsr[0][0]) + int64_t(S) * L + N - 1 <= n_in))   // DS:362 fails for row 0 ...
             return fail(OFDM_ERR_UNBOUND, "row 0 fails the data guard before any row passed (the reference raises UnboundLocalError, "
                                           "SynchEstFOAndDSSS.py:392)");                       // ... rows >= 1 of this call always pass
-        if (h->dmax_tmp_ind < 0)
+        if (h->d_rot && h->dmax_tmp_ind < 0)
             return fail(OFDM_ERR_INVALID, "no trial has ever been evaluated: dmax_tmp_ind is undefined (the reference raises NameError)");
         DemodArgs da{};
         da.iq = h->d_in;
@@ -926,7 +928,7 @@ int64_t ofdm_fo_work(ofdm_fo* h, const float* h_in, int64_t n_in, float* h_out, 
         da.row_stride_pat = 1;
         da.rows_per_frame = 1;
         da.zero_skipped = 0;
-        da.rot = h->d_rot + size_t(h->dmax_tmp_ind) * N;                                     // :339
+        da.rot = h->d_rot ? h->d_rot + size_t(h->dmax_tmp_ind) * N : nullptr;              // :339 (table mode: none)
         HIP_TRY(launch_rx_demod(d, da, s));
         if (h->cfg.dsss > 0)                                                                 // DS:391-399
             HIP_TRY(launch_despread(h->t_edf, Kd, h->d_code, h->cfg.dsss, h->n_spread, n_sync, h->t_edfd, s));

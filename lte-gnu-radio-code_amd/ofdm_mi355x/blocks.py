@@ -124,13 +124,19 @@ class synch_and_chan_est(SynchAndChanEst):  # noqa: N801  (reference class name)
     The reference implementation of this generation raises AttributeError/TypeError on its first
     detection under Python 3 (gr-RXOFDM/python/synch_and_chan_est.py:194,253); what is kept is its
     constructor signature and constants (ZC root 37, search stride cp-1, gate 0.4, linear snr) on the
-    gr-utsa_ofdm control flow.
+    gr-utsa_ofdm control flow.  ``table_mode=True`` selects the control flow its own work() spells out instead
+    (sync table, one data symbol per sync): see `synch_and_chan_est_table`.
     """
 
     _COMPAT = _lib.COMPAT_RXOFDM
 
+    def __new__(cls, *args, table_mode=False, **kw):
+        if table_mode and cls is synch_and_chan_est:
+            return synch_and_chan_est_table(*args, **kw)        # another class: __init__ below is not run again
+        return super().__new__(cls)
+
     def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
-                 directory_name, file_name_cest, diagnostics, genie):
+                 directory_name, file_name_cest, diagnostics, genie, table_mode=False):
         SynchAndChanEst.__init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
                                  0.4, directory_name, file_name_cest, diagnostics, genie)
         self.diagnostics = diagnostics
@@ -146,56 +152,36 @@ _FO_CASES = {
 }
 
 
-class SynchEstAndFO(sync_block):
-    """OFDMReceiver.SynchEstAndFO(case, fo_range, directory_name, file_name_cest, diagnostics) -- ZC timing sync with a
-    brute-force carrier-offset search, a table of up to 100 syncs per call, one equalised data symbol per sync.
+class _SyncTableBlock(sync_block):
+    """Shared body of the legacy-generation receivers that keep a TABLE of up to 100 syncs per work() call and demodulate
+    one data symbol per sync (SynchEstAndFO.py:232-369 == gr-RXOFDM synch_and_chan_est.py:136-266 minus the rotators)."""
 
-    The reference file is Python-2 code (`self.cp_len = self.nfft/4` is used as an index, :39,193): its `/` on ints is a
-    floor division, which also makes `(1/self.fs)` in :192 equal 0 -- every candidate rotator is exp(0) = 1 and the
-    search always picks index 0.  `py2_rotators=True` (default) keeps exactly that; `py2_rotators=False` builds the
-    evidently intended rotators exp(j 2 pi fo n / fs) (no reference output exists for it).
-    """
-
-    _CASES = _FO_CASES
-    _NAME = "SynchEstAndFO"
-
-    def __init__(self, case, fo_range, directory_name, file_name_cest, diagnostics, py2_rotators=True):
-        sync_block.__init__(self, name=self._NAME, in_sig=[np.complex64], out_sig=[np.complex64])
-        self.case = case
-        if case not in self._CASES:
-            # :136 prints "Error: Case Out of Bounds" and then fails on the first missing attribute
-            print("Error: Case Out of Bounds")
-            raise AttributeError("'%s' object has no attribute 'num_synch_bins'" % self._NAME)
-        self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = self._CASES[case][:5]
-        self.synch_dat = list(sd)
-        self.cp_len = self.nfft // 4
-        self.num_synch_bins = self.nfft - 2
-        self.SNR = 100000000
-        self.fo_range = fo_range
-        self.synch_bins_used_P = list(bins_p(self.num_synch_bins, self.nfft))   # :155-158
-        self.bins_used_P = list(bins_p(self.num_data_bins, self.nfft))          # :185-187
+    def _configure(self, name, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, rotators,
+                   directory_name, file_name_cest, diagnostics, spread_code=None):
+        sync_block.__init__(self, name=name, in_sig=[np.complex64], out_sig=[np.complex64])
+        self.num_ofdm_symb, self.nfft, self.cp_len = num_ofdm_symb, nfft, cp_len
+        self.num_synch_bins, self.num_data_bins = num_synch_bins, num_data_bins
+        self.synch_dat = list(synch_dat)
+        self.SNR = snr
+        self.synch_bins_used_P = list(bins_p(num_synch_bins, nfft))             # FO:155-158 / RXc:42-45
+        self.bins_used_P = list(bins_p(num_data_bins, nfft))                    # FO:185-187 / RXc:70-72
         self.L_synch = len(self.synch_bins_used_P)
-        self.M = [self.synch_dat[0], self.num_synch_bins]
+        self.M = [self.synch_dat[0], num_synch_bins]
         self.MM = int(np.prod(self.M))
-        self.p = 37                                                             # :167
-        self.zadoff_chu = zadoff_chu(self.MM, self.p, parity_of=self.num_synch_bins)
-        inv_fs = (1 // self.fs) if py2_rotators else (1.0 / self.fs)
-        self.cfo = np.exp(1j * 2 * np.pi * inv_fs * np.outer(list(fo_range), np.arange(self.nfft)))   # :192
-        self.stride_val = self.cp_len - 1                                       # :196
-        self.start_samp = self.cp_len
-        self.rx_b_len = self.nfft + self.cp_len
-        self.max_num_corr = _lib.FO_MAX_SYNC                                    # :200
+        self.p = 37                                                             # FO:167 / RXc:54
+        self.zadoff_chu = zadoff_chu(self.MM, self.p, parity_of=num_synch_bins)
+        self.stride_val = cp_len - 1                                            # FO:196 / RXc:81
+        self.start_samp = cp_len
+        self.rx_b_len = nfft + cp_len
+        self.max_num_corr = _lib.FO_MAX_SYNC                                    # FO:200 / RXc:85
         self.cor_obs = -1
         self.count = 0
         self.directory_name = directory_name
         self.file_name_cest = file_name_cest
         self.diagnostics = diagnostics
-        self._engine = FoEngine(self.num_ofdm_symb, self.nfft, self.cp_len, self.num_synch_bins, self.synch_dat,
-                                self.num_data_bins, self.SNR, self.cfo, device=_device(), spread_code=self._spread_code())
+        self._engine = FoEngine(num_ofdm_symb, nfft, cp_len, num_synch_bins, self.synch_dat, num_data_bins, snr, rotators,
+                                device=_device(), spread_code=spread_code)
         self._n_sync = 0
-
-    def _spread_code(self):
-        return None
 
     def _state(self, key):
         return self._engine.state()[key]
@@ -224,6 +210,9 @@ class SynchEstAndFO(sync_block):
     def eq_gain(self):
         return self._state("eq_gain").astype(complex)
 
+    def _dump_name(self, date_time):
+        return str(self.directory_name) + str(self.file_name_cest) + date_time + '.pckl'         # FO:312
+
     def work(self, input_items, output_items):
         in0 = input_items[0]
         out = output_items[0]
@@ -232,17 +221,65 @@ class SynchEstAndFO(sync_block):
         self.count = rep.count
         self._n_sync = rep.n_sync
         if rep.dmax_tmp_ind >= 0:
-            self.dmax_tmp_ind = rep.dmax_tmp_ind                                # :283 (absent until a trial has run)
+            self.dmax_tmp_ind = rep.dmax_tmp_ind                                # FO:283 (absent until a trial has run)
         if rc >= 0:
-            self.cor_obs = 0                                                    # :369
+            self.cor_obs = 0                                                    # FO:369
         n = _lib.check(rc)
-        if self.diagnostics == 1 and rep.n_sync > 0:                            # :308-314: dump of the latest estimate
+        if self.diagnostics == 1 and rep.n_sync > 0:                            # FO:308-314: dump of the latest estimate
             import datetime
             chan_est_tim = self.est_chan_time[rep.n_sync - 1][np.newaxis, :]
             date_time = datetime.datetime.now().strftime('%Y_%m_%d_%Hh_%Mm')
-            with open(str(self.directory_name) + str(self.file_name_cest) + date_time + '.pckl', 'wb') as f:
+            with open(self._dump_name(date_time), 'wb') as f:
                 pickle.dump(chan_est_tim, f, protocol=2)
         return n
+
+
+class synch_and_chan_est_table(_SyncTableBlock):  # noqa: N801
+    """gr-RXOFDM's synch_and_chan_est as its work() is written (synch_and_chan_est.py:136-266): every gate-passing trial
+    that is far enough from the previous sync enters a 100-row table, each sync is followed by ONE equalised data symbol,
+    and the first num_ofdm_symb/(S+D) rows are emitted from the second call on.  (As shipped the reference class dies on its
+    first detection -- :194 reads `self.diagnostic`, which the constructor never sets; the goldens were recorded with that
+    attribute supplied.)  Selected with ``RXOFDM.synch_and_chan_est(..., table_mode=True)``."""
+
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr,
+                 directory_name, file_name_cest, diagnostics, genie):
+        self.genie = genie
+        self._configure("SynchAndChanEst", num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, None,
+                        directory_name, file_name_cest, diagnostics)
+
+    def _dump_name(self, date_time):
+        return str(self.directory_name) + str(date_time) + str(self.file_name_cest) + '.pckl'    # RXc:206-207
+
+
+class SynchEstAndFO(_SyncTableBlock):
+    """OFDMReceiver.SynchEstAndFO(case, fo_range, directory_name, file_name_cest, diagnostics) -- ZC timing sync with a
+    brute-force carrier-offset search, a table of up to 100 syncs per call, one equalised data symbol per sync.
+
+    The reference file is Python-2 code (`self.cp_len = self.nfft/4` is used as an index, :39,193): its `/` on ints is a
+    floor division, which also makes `(1/self.fs)` in :192 equal 0 -- every candidate rotator is exp(0) = 1 and the
+    search always picks index 0.  `py2_rotators=True` (default) keeps exactly that; `py2_rotators=False` builds the
+    evidently intended rotators exp(j 2 pi fo n / fs) (no reference output exists for it).
+    """
+
+    _CASES = _FO_CASES
+    _NAME = "SynchEstAndFO"
+
+    def __init__(self, case, fo_range, directory_name, file_name_cest, diagnostics, py2_rotators=True):
+        self.case = case
+        if case not in self._CASES:
+            # :136 prints "Error: Case Out of Bounds" and then fails on the first missing attribute
+            print("Error: Case Out of Bounds")
+            raise AttributeError("'%s' object has no attribute 'num_synch_bins'" % self._NAME)
+        num_ofdm_symb, self.fs, nfft, sd, num_data_bins = self._CASES[case][:5]
+        self.fo_range = fo_range
+        inv_fs = (1 // self.fs) if py2_rotators else (1.0 / self.fs)
+        self.cfo = np.exp(1j * 2 * np.pi * inv_fs * np.outer(list(fo_range), np.arange(nfft)))   # :192
+        self.p = 37
+        self._configure(self._NAME, num_ofdm_symb, nfft, nfft // 4, nfft - 2, sd, num_data_bins, 100000000, self.cfo,
+                        directory_name, file_name_cest, diagnostics, spread_code=self._spread_code())
+
+    def _spread_code(self):
+        return None
 
 
 # SynchEstFOAndDSSS's case table (LEGACY/gr-ofdm-rx/python/SynchEstFOAndDSSS.py:37-157): ... + DSSS spreading factor

@@ -171,17 +171,19 @@ class FoEngine:
 
     def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, rotators, device=0,
                  spread_code=None):
-        """spread_code: None = SynchEstAndFO; a complex sequence of length DSSS = SynchEstFOAndDSSS (despread output)."""
+        """rotators: [len(fo_range)][nfft] candidate rotators, or None = no carrier-offset stage (gr-RXOFDM table mode).
+        spread_code: None = SynchEstAndFO; a complex sequence of length DSSS = SynchEstFOAndDSSS (despread output)."""
         self.lib = _lib.load()
-        rot = np.ascontiguousarray(rotators, dtype=np.complex64)
-        if rot.ndim != 2 or rot.shape[1] != int(nfft) or rot.shape[0] < 1:
+        rot = None if rotators is None else np.ascontiguousarray(rotators, dtype=np.complex64)
+        if rot is not None and (rot.ndim != 2 or rot.shape[1] != int(nfft) or rot.shape[0] < 1):
             raise ValueError("rotators must be [len(fo_range) >= 1][nfft]")
         code = None if spread_code is None else np.ascontiguousarray(spread_code, dtype=np.complex64).ravel()
         self.dsss = 0 if code is None else int(code.size)
         self.n_spread = int(num_data_bins) // self.dsss if self.dsss else 0
         self.cfg = _lib.FoCfg(int(num_ofdm_symb), int(nfft), int(cp_len), int(num_synch_bins), int(synch_dat[0]),
-                              int(synch_dat[1]), int(num_data_bins), int(rot.shape[0]), float(snr),
-                              rot.ctypes.data, int(device), self.dsss, None if code is None else code.ctypes.data)
+                              int(synch_dat[1]), int(num_data_bins), 1 if rot is None else int(rot.shape[0]), float(snr),
+                              None if rot is None else rot.ctypes.data, int(device), self.dsss,
+                              None if code is None else code.ctypes.data)
         h = C.c_void_p()
         check(self.lib.ofdm_fo_create(C.byref(self.cfg), C.byref(h)))
         self.cfg.rotators = None          # the library copied the tables

@@ -563,10 +563,30 @@ class FoOracle:
         is an INTEGER division (fs is an int) = 0, so every carrier-offset rotator is exp(0) = 1 and the search is a no-op
         (all candidates tie, index 0 wins).  py2_rotators=False uses 1.0/fs, the evidently intended rotators (unpinned)."""
         self.num_ofdm_symb, self.fs, self.nfft, sd, self.num_data_bins = self.CASES[case][:5]
+        self._setup(sd, self.nfft // 4, self.nfft - 2, 100000000, fo_range, py2_rotators)    # FO:39 (py2 int division)
+
+    @classmethod
+    def from_params(cls, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, force_fp64=False):
+        """The same receiver configured by constructor arguments and without a carrier-offset search: this is the work()
+        of gr-RXOFDM's synch_and_chan_est (RXc:136-266, "table mode"), which is SynchEstAndFO.work minus the rotators.
+        Without the rotator product the data window stays a complex64 slice: np.fft.fft then computes in single precision
+        under NumPy >= 2 (the oracle follows the installed NumPy literally; force_fp64=True is the yardstick for the GPU),
+        and a short slice is zero-padded by fft(x, N) instead of failing in the product (RXc:228-230)."""
+        o = cls.__new__(cls)
+        o.num_ofdm_symb, o.fs, o.nfft, o.num_data_bins = int(num_ofdm_symb), 1, int(nfft), int(num_data_bins)
+        o._setup(synch_dat, int(cp_len), int(num_synch_bins), snr, [0.0], True)
+        o._table_mode = True
+        o._force_fp64 = bool(force_fp64)
+        return o
+
+    _table_mode = False
+    _force_fp64 = False
+
+    def _setup(self, sd, cp_len, num_synch_bins, snr, fo_range, py2_rotators):
         self.synch_dat = [int(sd[0]), int(sd[1])]
-        self.cp_len = self.nfft // 4                                         # FO:39 (py2 int division)
-        self.num_synch_bins = self.nfft - 2
-        self.SNR = 100000000
+        self.cp_len = cp_len
+        self.num_synch_bins = num_synch_bins
+        self.SNR = snr
         self.fo_range = list(fo_range)
         self.synch_bins_used_P = bins_p(self.num_synch_bins, self.nfft)      # FO:155-158
         self.bins_used_P = bins_p(self.num_data_bins, self.nfft)             # FO:185-187
@@ -648,8 +668,13 @@ class FoOracle:
         if not (self.time_synch_ref[P][0] + S * L + N - 1 <= len(in0)):      # FO:334
             return None
         data_ptr = int(self.time_synch_ref[P][0] + S * L)                    # FO:335
-        x = in0[data_ptr: data_ptr + N] * self.cfo[self.dmax_tmp_ind]        # FO:338-339 (ValueError if the slice is short)
-        t_vec = np.fft.fft(x, N)                                             # FO:340
+        if self._table_mode:
+            x = in0[data_ptr: data_ptr + N]                                  # RXc:228
+            if self._force_fp64:
+                x = x.astype(np.complex128)
+        else:
+            x = in0[data_ptr: data_ptr + N] * self.cfo[self.dmax_tmp_ind]    # FO:338-339 (ValueError if the slice is short)
+        t_vec = np.fft.fft(x, N)                                             # FO:340 / RXc:230
         f0 = t_vec[self.bins_used_P]
         f0 = f0 * np.sqrt(len(f0) / np.dot(f0, np.conj(f0)))                 # FO:343-345
         f0 = f0 * np.exp((1j * (2 * np.pi / N)) * self.time_synch_ref[P][1] * self.bins_used_P)   # FO:347-350

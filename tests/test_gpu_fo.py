@@ -207,3 +207,56 @@ def test_dsss_block_unbound_local_like_the_reference():
         blk.work([short], [np.zeros(len(short), np.complex64)])
     with pytest.raises(AttributeError):
         _dsss_block(11, [0.0])
+
+
+# ------------------------------------------------------------------------------------------ gr-RXOFDM table mode
+@pytest.mark.parametrize("tag", ["chain", "s2", "n256"])
+def test_rxofdm_table_mode_on_reference_runs(golden, tag):
+    """RXOFDM.synch_and_chan_est(..., table_mode=True) vs recorded runs of gr-RXOFDM's own work()
+    (tests/golden/ref_rxofdm_table.npz; "chain" is the ofdm_chain.py:83 wiring with K = N sync bins)."""
+    import RXOFDM
+    g = golden("ref_rxofdm_table.npz")
+    p = g[tag + "_par"]
+    blk = RXOFDM.synch_and_chan_est(int(p[0]), int(p[1]), int(p[2]), int(p[3]), [int(p[4]), int(p[5])], int(p[6]), float(p[7]),
+                                    "/tmp/", "x", 0, 0, table_mode=True)
+    assert type(blk).__name__ == "synch_and_chan_est_table"
+    iq = g[tag + "_iq"]
+    for call in (1, 2):
+        out = np.zeros(len(iq), np.complex64)
+        assert blk.work([iq], [out]) == len(iq)
+        k = "%s_call%d_" % (tag, call)
+        _check_table(blk.time_synch_ref, g[k + "tsr"])
+        assert relerr(blk.est_chan_freq_P, g[k + "H"]) < TOL
+        assert relerr(blk.est_chan_time, g[k + "htime"]) < TOL
+        assert relerr(blk.est_synch_freq, g[k + "esf"]) < TOL
+        assert relerr(blk.est_data_freq, g[k + "edf"]) < TOL
+        if call == 1:
+            assert not out.any()
+        else:
+            assert relerr(out, g[k + "out"]) < TOL
+    # one data symbol per sync: de-maps to the first data symbol of every pattern
+    S, D, Kd = int(p[4]), int(p[5]), int(p[6])
+    n_sync = int(np.count_nonzero(blk.time_synch_ref[:, 2]))
+    got = orc.demap_hard(blk.est_data_freq[:n_sync].ravel(), "QPSK").reshape(n_sync, Kd * 2)
+    ref = g[tag + "_bits"].reshape(-1, Kd * 2)[0::D][:n_sync]
+    assert np.array_equal(got, ref)
+
+
+def test_rxofdm_table_mode_short_slice_is_zero_padded():
+    """Without the rotator product a data slice that is one sample short is zero-padded by fft(x, N) (RXc:228-230) where
+    SynchEstAndFO raises; same inputs as the FO error test, vs the oracle with the fp64 yardstick."""
+    import RXOFDM
+    par = (48, 64, 16, 62, (1, 1), 12, 1e8)
+    iq, _ = _make_input(0, 0.0, 0, False, 4)
+    o = orc.FoOracle.from_params(*par, force_fp64=True)
+    blk = RXOFDM.synch_and_chan_est(par[0], par[1], par[2], par[3], list(par[4]), par[5], par[6], "/tmp/", "x", 0, 0,
+                                    table_mode=True)
+    o.work(iq, np.zeros(len(iq), np.complex64))
+    blk.work([iq], [np.zeros(len(iq), np.complex64)])
+    short = iq[:int(o.time_synch_ref[0][0]) + 80 + 64 - 1]
+    ro, rb = np.zeros(len(iq), np.complex64), np.zeros(len(iq), np.complex64)      # room for the corr_size rows
+    o.work(short, ro)
+    blk.work([short], [rb])
+    _check_table(blk.time_synch_ref, o.time_synch_ref)
+    assert relerr(blk.est_data_freq, o.est_data_freq) < TOL
+    assert ro.any() and relerr(rb, ro) < TOL

@@ -63,3 +63,23 @@ def test_dsss_oracle_unbound_local_on_short_second_buffer():
     short = iq[:int(o.time_synch_ref[0][0]) + sd[0] * (N + N // 4) + N - 2]
     with pytest.raises(UnboundLocalError):
         o.work(short, np.zeros(len(short), np.complex64))
+
+
+@pytest.mark.parametrize("tag", ["chain", "s2", "n256"])
+def test_table_mode_oracle_matches_gr_rxofdm_runs(golden, tag):
+    """FoOracle.from_params (no carrier-offset search) vs recorded runs of gr-RXOFDM's synch_and_chan_est.work
+    (tests/golden/gen_golden_rxofdm_table.py; the instance is given the `diagnostic` attribute its constructor forgets)."""
+    g = golden("ref_rxofdm_table.npz")
+    p = g[tag + "_par"]
+    o = orc.FoOracle.from_params(int(p[0]), int(p[1]), int(p[2]), int(p[3]), (int(p[4]), int(p[5])), int(p[6]), float(p[7]))
+    iq = g[tag + "_iq"]
+    for call in (1, 2):
+        out = np.zeros(len(iq), np.complex64)
+        assert o.work(iq, out) == len(iq)
+        k = "%s_call%d_" % (tag, call)
+        assert np.array_equal(o.time_synch_ref, g[k + "tsr"])
+        assert relerr(o.est_chan_freq_P, g[k + "H"]) < 1e-12
+        assert relerr(o.est_chan_time, g[k + "htime"]) < 1e-12
+        assert relerr(o.est_synch_freq, g[k + "esf"]) < 1e-12
+        assert relerr(o.est_data_freq, g[k + "edf"]) < 1e-11
+        assert relerr(out, g[k + "out"]) < 1e-6 or not g[k + "out"].any()
