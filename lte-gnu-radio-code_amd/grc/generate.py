@@ -45,6 +45,14 @@ BLOCKS = [
          cls="BitRecovery",
          params=[("modulation", "Modulation", "string"), ("directory_name", "Directory", "string"), ("diagnostics", "Diagnostics", "int")],
          make_args=["modulation", "directory_name", "diagnostics"], inputs=CPLX_IN, outputs=None),
+    dict(id="OFDMReceiver_SynchAndChanEst", label="SynchAndChanEst (MI355X)", category="[OFDMReceiver]", module="OFDMReceiver",
+         cls="SynchAndChanEst",
+         params=[("num_ofdm_symb", "No. of OFDM Symbols", "int"), ("nfft", "FFT Size", "int"), ("cp_len", "CP Length", "int"),
+                 ("num_synch_bins", "No. of Synch Bins", "int"), ("synch_dat", "Synch-Data Pattern", "raw"),
+                 ("num_data_bins", "No. of Data Bins", "int"), ("SNR", "SNR", "float"), ("directory_name", "Directory Path", "string"),
+                 ("file_name_cest", "Var: Chan Est -- File Name", "string"), ("diagnostics", "Diagnostics", "int")],
+         make_args=["num_ofdm_symb", "nfft", "cp_len", "num_synch_bins", "synch_dat", "num_data_bins", "SNR", "directory_name",
+                    "file_name_cest", "diagnostics"], inputs=CPLX_IN, outputs=CPLX_IN),
     dict(id="OFDMReceiver_SynchEstAndFO", label="SynchEstAndFO (MI355X)", category="[OFDMReceiver]", module="OFDMReceiver",
          cls="SynchEstAndFO",
          params=[("case", "Case Number", "int"), ("fo_range", "F Offset Range", "raw"), ("directory_name", "Directory Path", "string"),

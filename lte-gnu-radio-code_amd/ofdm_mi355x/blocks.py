@@ -251,6 +251,18 @@ class synch_and_chan_est_table(_SyncTableBlock):  # noqa: N801
         return str(self.directory_name) + str(date_time) + str(self.file_name_cest) + '.pckl'    # RXc:206-207
 
 
+class LegacySynchAndChanEst(synch_and_chan_est_table):
+    """OFDMReceiver.SynchAndChanEst(num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, SNR, directory_name,
+    file_name_cest, diagnostics) -- LEGACY/gr-ofdm-rx/python/SynchAndChanEst.py:28-243: the same work() as gr-RXOFDM's
+    block (sync table, one data symbol per sync) without its broken genie branch; it runs unmodified under Python 2 and is
+    bit-identical to the recorded gr-RXOFDM runs (tests/golden/gen_golden_rxofdm_table.py)."""
+
+    def __init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, SNR, directory_name,
+                 file_name_cest, diagnostics):
+        synch_and_chan_est_table.__init__(self, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, SNR,
+                                          directory_name, file_name_cest, diagnostics, 0)
+
+
 class SynchEstAndFO(_SyncTableBlock):
     """OFDMReceiver.SynchEstAndFO(case, fo_range, directory_name, file_name_cest, diagnostics) -- ZC timing sync with a
     brute-force carrier-offset search, a table of up to 100 syncs per call, one equalised data symbol per sync.

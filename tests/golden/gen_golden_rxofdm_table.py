@@ -19,6 +19,8 @@ import gen_golden_fo as G
 from oracle import ofdm_oracle as orc
 
 PATH = "/root/reference/GNU-Radio-Repositories/gr-RXOFDM/python/synch_and_chan_est.py"
+# the LEGACY module's block of the same name has the identical work() without the broken genie branch and runs unmodified
+PATH_LEGACY = "/root/reference/GNU-Radio-Repositories/LEGACY/gr-ofdm-rx/python/SynchAndChanEst.py"
 
 CASES = [
     # tag, (num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr), n_sym sent, lead, fading
@@ -42,11 +44,14 @@ def make_input(par, n_sym, lead, fading, seed):
 
 def main():
     cls = G.load_reference_class(PATH, "synch_and_chan_est")
+    cls_legacy = G.load_reference_class(PATH_LEGACY, "SynchAndChanEst")
     out = {}
     for i, (tag, par, n_sym, lead, fading) in enumerate(CASES):
         iq, bits = make_input(par, n_sym, lead, fading, 500 + i)
         blk = cls(par[0], par[1], par[2], par[3], list(par[4]), par[5], par[6], "/tmp/", "x", 0, 0)
         blk.diagnostic = 0            # the attribute :194 reads and the constructor forgets
+        leg = cls_legacy(par[0], par[1], par[2], par[3], list(par[4]), par[5], par[6], "/tmp/", "x", 0)   # nothing patched
+        same = True
         out[tag + "_iq"] = iq
         out[tag + "_bits"] = bits.astype(np.uint8)
         out[tag + "_par"] = np.array([par[0], par[1], par[2], par[3], par[4][0], par[4][1], par[5], par[6]], dtype=np.float64)
@@ -63,6 +68,15 @@ def main():
             out[k + "esf"] = blk.est_synch_freq.copy()
             out[k + "edf"] = blk.est_data_freq.copy()
             out[k + "out"] = o
+            o2 = np.zeros(len(iq), np.complex64)
+            with contextlib.redirect_stdout(io.StringIO()):
+                leg.work([iq], [o2])
+            same = same and all(np.array_equal(a, b) for a, b in (
+                (leg.time_synch_ref, blk.time_synch_ref), (leg.est_chan_freq_P, blk.est_chan_freq_P),
+                (leg.est_chan_time, blk.est_chan_time), (leg.est_synch_freq, blk.est_synch_freq),
+                (leg.est_data_freq, blk.est_data_freq), (o2, o)))
+        print(tag, "unmodified LEGACY OFDMReceiver.SynchAndChanEst bit-identical:", same)
+        out[tag + "_legacy_identical"] = np.array([int(same)])
     np.savez_compressed(os.path.join(G.HERE, "ref_rxofdm_table.npz"), **out)
 
 

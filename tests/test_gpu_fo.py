@@ -220,10 +220,18 @@ def test_rxofdm_table_mode_on_reference_runs(golden, tag):
     blk = RXOFDM.synch_and_chan_est(int(p[0]), int(p[1]), int(p[2]), int(p[3]), [int(p[4]), int(p[5])], int(p[6]), float(p[7]),
                                     "/tmp/", "x", 0, 0, table_mode=True)
     assert type(blk).__name__ == "synch_and_chan_est_table"
+    # the unmodified LEGACY OFDMReceiver.SynchAndChanEst produced bit-identical arrays when the goldens were recorded
+    assert int(g[tag + "_legacy_identical"][0]) == 1
+    import OFDMReceiver
+    leg = OFDMReceiver.SynchAndChanEst(int(p[0]), int(p[1]), int(p[2]), int(p[3]), [int(p[4]), int(p[5])], int(p[6]), float(p[7]),
+                                       "/tmp/", "x", 0)
     iq = g[tag + "_iq"]
     for call in (1, 2):
         out = np.zeros(len(iq), np.complex64)
         assert blk.work([iq], [out]) == len(iq)
+        out_l = np.zeros(len(iq), np.complex64)
+        leg.work([iq], [out_l])
+        assert np.array_equal(out_l, out) and np.array_equal(leg.est_data_freq, blk.est_data_freq)
         k = "%s_call%d_" % (tag, call)
         _check_table(blk.time_synch_ref, g[k + "tsr"])
         assert relerr(blk.est_chan_freq_P, g[k + "H"]) < TOL

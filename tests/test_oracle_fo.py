@@ -70,6 +70,7 @@ def test_table_mode_oracle_matches_gr_rxofdm_runs(golden, tag):
     """FoOracle.from_params (no carrier-offset search) vs recorded runs of gr-RXOFDM's synch_and_chan_est.work
     (tests/golden/gen_golden_rxofdm_table.py; the instance is given the `diagnostic` attribute its constructor forgets)."""
     g = golden("ref_rxofdm_table.npz")
+    assert int(g[tag + "_legacy_identical"][0]) == 1      # same arrays from the unmodified LEGACY OFDMReceiver.SynchAndChanEst
     p = g[tag + "_par"]
     o = orc.FoOracle.from_params(int(p[0]), int(p[1]), int(p[2]), int(p[3]), (int(p[4]), int(p[5])), int(p[6]), float(p[7]))
     iq = g[tag + "_iq"]
