@@ -743,3 +743,150 @@ class FoDsssOracle(FoOracle):
         self.count += 1
         self.cor_obs = 0
         return len(out)
+
+
+# --------------------------------------------------------------------------- regression-tracking receiver
+# SE = G/LEGACY/gr-ofdm-rx/python/SynchronizeAndEstimate.py
+TRACKER_PROFILES = {
+    # case -> (channel_band, bin_spacing, num_ant_txrx, SNR, num_symbols[0])   (SE:33-60)
+    0: (0.97 * 960e3, 15e3, 1, 100, 48),
+    1: (0.9 * 20e6, 312.5e3, 2, 50, 10),
+}
+
+
+class TrackerOracle:
+    """fp64 restatement of SynchronizeAndEstimate (SE:25-442): acquisition by a strided ZC lag-correlation search, then one
+    sync symbol per [1,3] pattern at a pointer that is first advanced by the pattern length and, from the sixth sync on,
+    predicted by a least-squares line through the last five (position + lag) observations (SE:333-350); LS channel estimate
+    per sync; three equalised data symbols per sync, each renormalised by the power of est_data_freq row `p` (SE:431-434).
+
+    Kept literally: the lag is reported minus one (`dmax_ind = dmax_ind0 - 1`, SE:275) and a lag of -1 indexes the LAST column
+    of the phase matrix in the estimate (SE:354) but de-rotates the data by -1 (SE:421); the "late lag" branch moves the
+    pointer by cp/2 but recomputes the FFT of the SAME window (SE:281-309); the distance rule reads row max(corr_obs, 1),
+    which is a row of the PREVIOUS call for the first two syncs (SE:311-313); time_synch_ref[.., 2] holds the raw peak.
+    Case 1 (two antennas) runs the sync stage only (SE:397: the data stage is single-antenna)."""
+
+    def __init__(self, case):
+        band, spacing, self.num_ant_txrx, self.SNR, n_symb = TRACKER_PROFILES[case]
+        self.synch_data = np.array([1, 3])
+        self.NFFT = int(2 ** (np.ceil(np.log2(round(band / spacing)))))          # SE:83
+        self.len_CP = int(round(self.NFFT / 4))                                  # SE:85
+        num_bins1 = 4 * np.floor(np.floor(band / spacing) / 4)                   # SE:87-90
+        all_bins = np.array(list(range(-int(num_bins1 / 2), 0)) + list(range(1, int(num_bins1 / 2) + 1)))
+        self.num_data_bins = len(all_bins)                                       # ref_sigs = 0: no pilot bins (SE:80,95-101)
+        self.used_bins_data = ((self.NFFT + all_bins) % self.NFFT).astype(int)   # SE:102
+        n_pat = int(np.ceil(n_symb / sum(self.synch_data)))                      # SE:104
+        self.lmax_s, self.lmax_d = n_pat * 1, n_pat * 3                          # SE:143-144
+        self.rx_buff_len = self.NFFT + self.len_CP
+        self.num_synch_bins = self.NFFT - 2
+        self.MM = int(self.synch_data[0] * self.num_synch_bins)
+        self.synch_ref = zadoff_chu(self.MM, 23)                                 # SE:123-130
+        self.used_bins_synch = bins_p(self.num_synch_bins, self.NFFT)            # SE:134-136
+        a, N = self.num_ant_txrx, self.NFFT
+        self.est_chan_freq_p = np.zeros((a, self.lmax_s, N), dtype=complex)
+        self.est_chan_freq_n = np.zeros((a, self.lmax_s, self.num_synch_bins), dtype=complex)
+        self.est_synch_freq = np.zeros((a, self.lmax_s, self.num_synch_bins), dtype=complex)
+        self.est_chan_impulse = np.zeros((a, self.lmax_s, N), dtype=complex)
+        if a == 1:
+            self.est_data_freq = np.zeros((a, self.lmax_d, self.num_data_bins), dtype=complex)
+        self.time_synch_ref = np.zeros((a, 250, 3))                              # SE:179
+        self.corr_obs = None
+        self.force_fp64 = False
+
+    def _trial(self, in0, ptr_frame):
+        """Window at ptr_frame -> (normalised sync-bin vector, phase matrix, peak, arg-peak)  (SE:236-276)."""
+        N = self.NFFT
+        start = int(ptr_frame)
+        w = np.zeros(N, dtype=complex)
+        w[:] = in0[start:start + N]                                              # SE:240-243 (cast to complex128)
+        f = np.fft.fft(w, N)[self.used_bins_synch]
+        pow_est = np.sum(f * np.conj(f)).real / len(f)                           # SE:255
+        synch_dat = f / np.sqrt(pow_est)
+        p_mat = np.exp(1j * 2 * (np.pi / N) * np.outer(self.used_bins_synch, np.arange(self.len_CP + 1)))   # SE:264-268
+        del_mat = np.conj(self.synch_ref) @ (synch_dat[:, None] * p_mat)         # SE:271
+        dd = np.abs(del_mat)
+        return synch_dat, p_mat, dd.max(), int(dd.argmax())
+
+    def work(self, in0, out):
+        in0 = np.asarray(in0)
+        n_in = in0.shape[0]
+        N, cp, L, m = self.NFFT, self.len_CP, self.rx_buff_len, 0
+        stride_val = np.ceil(cp / 2)                                             # SE:209
+        ptr_frame, b, xp = 0, 0, []
+        self.corr_obs = -1                                                       # SE:216
+        start_samp = (cp - 4) - 1                                                # SE:219
+        total_loops = int(np.ceil(n_in / stride_val))
+        ptr_adj, loop_count, sym_count = 0, 0, 0
+        tap_delay = 5
+        x = np.zeros(tap_delay)
+        ptr_synch0 = np.zeros(1000)
+        sd = int(sum(self.synch_data))
+        while loop_count <= total_loops:                                         # SE:230
+            if self.corr_obs == -1:
+                ptr_frame = loop_count * stride_val + start_samp + ptr_adj
+            elif self.corr_obs < 5:
+                ptr_frame += sd * (N + cp)
+            else:
+                ptr_frame = (np.ceil(np.dot(xp[-1:], b) - cp / 4))[0]           # SE:237
+            if N + ptr_frame < n_in:                                             # SE:240 (M[0] = 1)
+                synch_dat, p_mat, dmax, dmax_ind0 = self._trial(in0, ptr_frame)
+                dmax_ind = dmax_ind0 - 1                                         # SE:275
+                if dmax > 0.5 * len(synch_dat) or self.corr_obs > -1:            # SE:279
+                    if dmax_ind > np.ceil(0.75 * cp):                            # SE:281: pointer moves, window does not
+                        if self.corr_obs == -1:
+                            ptr_adj += np.ceil(0.5 * cp)
+                            ptr_frame = loop_count * stride_val + start_samp + ptr_adj
+                        elif self.corr_obs < 5:
+                            ptr_frame += np.ceil(0.5 * cp)
+                    time_synch_ind = self.time_synch_ref[m, max(self.corr_obs, 1), 0]           # SE:311
+                    if ptr_frame - time_synch_ind > (2 * cp + N) or self.corr_obs == -1:        # SE:313
+                        self.corr_obs += 1
+                        self.time_synch_ref[m, self.corr_obs] = [ptr_frame, dmax_ind, dmax]     # SE:316-318
+                        ptr_synch0[sym_count % tap_delay] = sum(self.time_synch_ref[m, self.corr_obs, 0:2])
+                        x[sym_count % tap_delay] = sym_count * sd
+                        sym_count += 1
+                        x2 = x[0:min(self.corr_obs, tap_delay)]
+                        x_plus = np.concatenate((x2, np.atleast_1d(sym_count * sd)))
+                        xp = np.zeros((len(x_plus), 2))
+                        xp[:, 0] = 1
+                        xp[:, 1] = x_plus
+                        if self.corr_obs > 3:                                    # SE:333-341
+                            y = ptr_synch0[0:min(tap_delay, self.corr_obs)]
+                            X = np.zeros((len(x2), 2))
+                            X[:, 0] = 1
+                            X[:, 1] = x2
+                            b = np.linalg.lstsq(X, y, rcond=-1)[0]               # the reference's (legacy-default) rcond
+                        data_recov0 = synch_dat * p_mat[:, dmax_ind]             # SE:344 (-1 -> last column)
+                        h_est = (data_recov0 * np.conj(self.synch_ref)) / (1 + (1 / self.SNR))   # SE:348-353 (M[0] = 1)
+                        h_est1 = np.zeros(N, dtype=complex)
+                        h_est1[self.used_bins_synch] = h_est
+                        self.est_chan_freq_p[m, self.corr_obs] = h_est1          # IndexError past lmax_s rows
+                        self.est_chan_freq_n[m, self.corr_obs] = h_est
+                        self.est_chan_impulse[m, self.corr_obs] = np.fft.ifft(h_est1, N)        # SE:369-370
+                        self.est_synch_freq[m, self.corr_obs] = (data_recov0 * np.conj(h_est)) / (
+                            (np.conj(h_est) * h_est) + (1 / self.SNR))           # SE:375-378
+            loop_count += 1
+        if self.num_ant_txrx == 1:                                               # SE:397
+            D = int(self.synch_data[1])
+            for p in range(self.corr_obs + 1):
+                for data_sym in range(D):
+                    if sum(self.time_synch_ref[m, p, :]) + N < n_in:             # SE:401 (pointer + lag + PEAK)
+                        data_ptr = int(self.time_synch_ref[m, p, 0] + (data_sym + 1) * L)
+                        seg = in0[data_ptr: data_ptr + N]                        # complex64 slice; fft(x, N) zero-pads
+                        if self.force_fp64:
+                            seg = seg.astype(np.complex128)
+                        freq_dat0 = np.fft.fft(seg, N)[self.used_bins_data]
+                        # builtin sum, as the reference: on a complex64 vector (NumPy >= 2) it also ACCUMULATES in single
+                        # precision; force_fp64 is the yardstick for the GPU
+                        p_est = sum(freq_dat0 * np.conj(freq_dat0)) / len(freq_dat0)             # SE:411
+                        data_recov0 = freq_dat0 / np.sqrt(p_est)
+                        h_est = self.est_chan_freq_p[m, p, self.used_bins_data]
+                        data_recov = data_recov0 * np.exp(
+                            1j * 2 * (np.pi / N) * self.used_bins_data * self.time_synch_ref[m, p, 1])   # SE:420-422
+                        row = p * D + data_sym
+                        self.est_data_freq[m, row] = (data_recov * np.conj(h_est)) / ((np.conj(h_est) * h_est) + (1 / self.SNR))
+                        data = self.est_data_freq[m, p]                          # SE:431: row p, not the row just written
+                        p_est1 = sum(data * np.conj(data)) / len(data)
+                        self.est_data_freq[m, row] = self.est_data_freq[m, row] / np.sqrt(p_est1)
+                        out[0:self.num_data_bins] = self.est_data_freq[m, row]   # SE:438-440: every symbol lands at out[0:Kd]
+        return len(out)
