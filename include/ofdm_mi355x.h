@@ -226,6 +226,46 @@ int ofdm_fo_get_state(ofdm_fo* h, double* h_tsr, float* h_chan_freq, float* h_ch
  * h_data_freq_d[100][floor(Kd/DSSS)] complex64 interleaved. */
 int ofdm_fo_get_despread(ofdm_fo* h, float* h_data_freq_d);
 
+/* ------------------------------------------------ regression-tracking receiver */
+/* Device primitives behind OFDMReceiver.SynchronizeAndEstimate (G/LEGACY/gr-ofdm-rx/python/SynchronizeAndEstimate.py:25-442).
+ * The block's control flow is a strictly sequential pointer tracker (each window position depends on the outcome of the
+ * previous one, from the sixth sync on through a least-squares line, :230-350); that scalar logic stays in the host-side
+ * block mirror, which calls these entry points for every array computation: the strided acquisition search and the
+ * per-sync trial (:236-276), the LS estimate (:344-378) and the data stage (:397-440).  [1,3]-type patterns with ONE sync
+ * symbol per pattern only (the reference's reshape at :351 does not work for more). */
+typedef struct ofdm_trk ofdm_trk;
+typedef struct ofdm_trk_cfg {
+    int32_t nfft, cp_len;
+    int32_t num_synch_bins;    /* nfft - 2 (:122)                                                               */
+    int32_t num_data_bins;
+    int32_t synch_D;           /* data symbols per pattern (3)                                                   */
+    int32_t rows_sync;         /* lmax_s: rows of est_chan_freq_p / est_synch_freq / est_chan_impulse (:143)     */
+    int32_t rows_data;         /* lmax_d: rows of est_data_freq (:144)                                           */
+    int32_t zc_root;           /* 23 (:125)                                                                      */
+    double snr;                /* linear (:349,377,425)                                                          */
+    int32_t device;
+    int32_t reserved;
+} ofdm_trk_cfg;
+int ofdm_trk_create(const ofdm_trk_cfg* cfg, ofdm_trk** out);
+int ofdm_trk_destroy(ofdm_trk* h);
+/* work() buffer -> HBM; kept until the next load */
+int ofdm_trk_load(ofdm_trk* h, const float* h_in, int64_t n_in);
+/* `count` windows at first_ptr + i*step: h_peak[i] = max_d |del_mat[d]|, h_lag[i] = argmax d in 0..cp (:236-274).
+ * The caller vouches that every window lies inside the buffer (:240). */
+int ofdm_trk_trials(ofdm_trk* h, int64_t first_ptr, int32_t step, int32_t count, float* h_peak, int32_t* h_lag);
+/* LS estimate of the window at window_ptr into row `row` (:344-378): est_chan_freq_p, est_chan_impulse, est_synch_freq
+ * with the phase column lag_sync, and the data equaliser of that row de-rotated by lag_data (:421, may be -1).
+ * row >= rows_sync -> OFDM_ERR_INDEX (the reference raises IndexError at :358). */
+int ofdm_trk_accept(ofdm_trk* h, int32_t row, int64_t window_ptr, int32_t lag_sync, int32_t lag_data);
+/* Data stage (:397-440) for syncs 0..n_sync-1: h_ptr[p] = time_synch_ref[p][0]; h_guard[p] != 0 iff :401 holds.  Rows
+ * p*D+n of est_data_freq are equalised and renormalised in loop order; h_last[Kd] receives the last row processed (what
+ * lands in out[0:Kd], :438-440), *last_row its index or -1.  A row past rows_data -> OFDM_ERR_INDEX; an empty data slice
+ * -> OFDM_ERR_SHAPE (np.fft.fft raises ValueError); shorter slices are zero-padded like fft(x, N). */
+int ofdm_trk_demod(ofdm_trk* h, int32_t n_sync, const int64_t* h_ptr, const uint8_t* h_guard, float* h_last, int32_t* last_row);
+/* complex64 interleaved, any pointer may be NULL: h_chan_freq[rows_sync][nfft], h_chan_impulse[rows_sync][nfft],
+ * h_synch_freq[rows_sync][Ks], h_data_freq[rows_data][Kd] */
+int ofdm_trk_get_state(ofdm_trk* h, float* h_chan_freq, float* h_chan_impulse, float* h_synch_freq, float* h_data_freq);
+
 /* ------------------------------------------------------------------------------------------ misc */
 /* Measurement aid for bench.py: mode 0 = float4 device copy of `bytes` (achievable HBM rate of this chip, same run);
  * mode 1 = the demod kernel's access pattern without arithmetic (per symbol: skip gap_bytes, read sym_in_bytes, write

@@ -176,6 +176,27 @@ struct ofdm_fo {
     static constexpr int TRIAL_WIN = 256;
 };
 
+struct ofdm_trk {
+    ofdm_trk_cfg cfg{};
+    hipStream_t stream = nullptr;
+    RxDev dev{};
+    cf* d_tw = nullptr;
+    cf* d_zc = nullptr;
+    cf* d_in = nullptr;
+    int64_t in_cap = 0;
+    int64_t n_in = 0;
+    int* t_tsr = nullptr;                // [rows_sync][4]
+    cf* t_H = nullptr;                   // [rows_sync][N]
+    cf* t_imp = nullptr;                 // [rows_sync][N]
+    cf* t_esf = nullptr;                 // [rows_sync][Ks]
+    cf* t_gain = nullptr;                // [rows_sync][Kd]
+    cf* t_edf = nullptr;                 // [rows_data][Kd]
+    cf* s_ysc = nullptr;                 // [Ks]
+    float* d_trial_m = nullptr;
+    int* d_trial_d = nullptr;
+    static constexpr int TRIAL_CAP = 4096;
+};
+
 struct ofdm_tx {
     ofdm_tx_cfg cfg{};
     hipStream_t stream = nullptr;
@@ -980,6 +1001,239 @@ int ofdm_fo_get_despread(ofdm_fo* h, float* h_data_freq_d) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h_data_freq_d, h->t_edfd, size_t(OFDM_FO_MAX_SYNC) * h->n_spread * sizeof(cf), hipMemcpyDeviceToHost));
+    return OFDM_OK;
+}
+
+// ================================================================== regression-tracking receiver (device primitives)
+int ofdm_trk_destroy(ofdm_trk* h) {
+    if (!h) return OFDM_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_tw, h->d_zc, h->d_in, h->t_tsr, h->t_H, h->t_imp, h->t_esf, h->t_gain, h->t_edf, h->s_ysc,
+                    h->d_trial_m, h->d_trial_d};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return OFDM_OK;
+}
+
+int ofdm_trk_create(const ofdm_trk_cfg* c, ofdm_trk** out) {
+    if (!c || !out) return fail(OFDM_ERR_INVALID, "ofdm_trk_create: null argument");
+    *out = nullptr;
+    if (!supported_nfft(c->nfft)) return fail(OFDM_ERR_INVALID, "nfft=%d unsupported (64,128,...,4096)", c->nfft);
+    if (c->cp_len < 1 || c->cp_len >= c->nfft) return fail(OFDM_ERR_INVALID, "cp_len=%d out of range", c->cp_len);
+    if (c->num_synch_bins < 2 || c->num_synch_bins > c->nfft || (c->num_synch_bins & 1))
+        return fail(OFDM_ERR_INVALID, "num_synch_bins=%d must be even and in [2, nfft]", c->num_synch_bins);
+    if (c->num_data_bins < 2 || c->num_data_bins > c->nfft || (c->num_data_bins & 1))
+        return fail(OFDM_ERR_INVALID, "num_data_bins=%d must be even and in [2, nfft]", c->num_data_bins);
+    if (c->synch_D < 1 || c->rows_sync < 1 || c->rows_data < 0) return fail(OFDM_ERR_INVALID, "bad pattern / row counts");
+    if (!(c->snr > 0.0)) return fail(OFDM_ERR_INVALID, "snr must be > 0 (linear)");
+
+    HIP_TRY(hipSetDevice(c->device));
+    ofdm_trk* h = new (std::nothrow) ofdm_trk();
+    if (!h) return fail(OFDM_ERR_NOMEM, "out of host memory");
+    h->cfg = *c;
+    RxDev& d = h->dev;
+    const int N = c->nfft, Ks = c->num_synch_bins, Kd = c->num_data_bins;
+    d.nfft = N;
+    d.cp = c->cp_len;
+    d.L = N + c->cp_len;
+    d.Ks = Ks;
+    d.Kd = Kd;
+    d.S = 1;
+    d.D = c->synch_D;
+    d.MM = Ks;
+    d.bps = 2;
+    d.stride = 1;
+    d.gate_mm = 0.f;
+    d.inv_ls = float(1.0 / (1.0 + 1.0 / c->snr));                     // SynchronizeAndEstimate.py:349
+    d.inv_snr_data = float(1.0 / c->snr);                              // :425
+    d.inv_snr_eqsync = float(1.0 / c->snr);                            // :377
+    const size_t RS = size_t(c->rows_sync), RD = size_t(c->rows_data > 0 ? c->rows_data : 1);
+
+    int rc = OFDM_OK;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = fail(OFDM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    auto tw = make_twiddles(N);
+    auto zc = make_zc(Ks, c->zc_root, Ks);                             // :123-130 parity of MM = Ks
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(Ks));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_tsr, RS * 4);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_H, RS * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_imp, RS * N);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_esf, RS * Ks);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_gain, RS * Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->t_edf, RD * Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->s_ysc, size_t(Ks));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_m, size_t(ofdm_trk::TRIAL_CAP));
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_trial_d, size_t(ofdm_trk::TRIAL_CAP));
+    if (rc == OFDM_OK) {
+        bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemset(h->t_tsr, 0, RS * 4 * sizeof(int)) == hipSuccess &&
+                  hipMemset(h->t_H, 0, RS * N * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_imp, 0, RS * N * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_esf, 0, RS * Ks * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_gain, 0, RS * Kd * sizeof(cf)) == hipSuccess &&
+                  hipMemset(h->t_edf, 0, RD * Kd * sizeof(cf)) == hipSuccess;
+        if (!ok) rc = fail(OFDM_ERR_HIP, "device table initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (rc != OFDM_OK) {
+        std::string keep = g_last_error;
+        ofdm_trk_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    d.tw = h->d_tw;
+    d.zc = h->d_zc;
+    *out = h;
+    return OFDM_OK;
+}
+
+int ofdm_trk_load(ofdm_trk* h, const float* h_in, int64_t n_in) {
+    if (!h || (!h_in && n_in > 0) || n_in < 0) return fail(OFDM_ERR_INVALID, "ofdm_trk_load: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (n_in > h->in_cap) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_in) (void)hipFree(h->d_in);
+        h->d_in = nullptr;
+        h->in_cap = 0;
+        const int64_t cap = n_in + n_in / 4 + 1024;
+        int rc = dev_alloc(&h->d_in, size_t(cap));
+        if (rc != OFDM_OK) return rc;
+        h->in_cap = cap;
+    }
+    if (n_in > 0) HIP_TRY(hipMemcpyAsync(h->d_in, h_in, size_t(n_in) * sizeof(cf), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the caller's buffer is only valid during work()
+    h->n_in = n_in;
+    return OFDM_OK;
+}
+
+int ofdm_trk_trials(ofdm_trk* h, int64_t first_ptr, int32_t step, int32_t count, float* h_peak, int32_t* h_lag) {
+    if (!h || !h_peak || !h_lag || count < 0 || step < 1 || first_ptr < 0)
+        return fail(OFDM_ERR_INVALID, "ofdm_trk_trials: bad argument");
+    if (count == 0) return OFDM_OK;
+    const RxDev& d0 = h->dev;
+    if (first_ptr + int64_t(count - 1) * step + d0.nfft > h->n_in)
+        return fail(OFDM_ERR_INVALID, "window %lld..+%d reaches past the loaded buffer (%lld samples)",
+                    (long long)(first_ptr + int64_t(count - 1) * step), d0.nfft, (long long)h->n_in);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    RxDev d = d0;
+    d.stride = step;
+    for (int32_t done = 0; done < count; done += ofdm_trk::TRIAL_CAP) {
+        const int cnt = std::min<int>(ofdm_trk::TRIAL_CAP, count - done);
+        SyncArgs sa{};
+        sa.iq = h->d_in;
+        sa.frame_stride = h->n_in;
+        sa.frame_len = h->n_in;
+        sa.n_frames = 1;
+        sa.mode = 1;
+        sa.p_begin = done;
+        sa.p_count = cnt;
+        sa.off_delta = int(first_ptr) - d.cp;                         // window start = first_ptr + P*step
+        sa.host_valid = 1;
+        sa.trial_m = h->d_trial_m;
+        sa.trial_d = h->d_trial_d;
+        HIP_TRY(launch_rx_sync(d, sa, h->stream));
+        HIP_TRY(hipMemcpyAsync(h_peak + done, h->d_trial_m, size_t(cnt) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h_lag + done, h->d_trial_d, size_t(cnt) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return OFDM_OK;
+}
+
+int ofdm_trk_accept(ofdm_trk* h, int32_t row, int64_t window_ptr, int32_t lag_sync, int32_t lag_data) {
+    if (!h || row < 0 || window_ptr < 0) return fail(OFDM_ERR_INVALID, "ofdm_trk_accept: bad argument");
+    const RxDev& d = h->dev;
+    if (row >= h->cfg.rows_sync)
+        return fail(OFDM_ERR_INDEX, "est_chan_freq_p has %d rows, corr_obs=%d (the reference raises IndexError)", h->cfg.rows_sync, row);
+    if (lag_sync < 0 || lag_sync > d.cp || window_ptr + d.nfft > h->n_in) return fail(OFDM_ERR_INVALID, "ofdm_trk_accept: lag / window out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int N = d.nfft;
+    SyncArgs fa{};
+    fa.iq = h->d_in;
+    fa.frame_stride = h->n_in;
+    fa.frame_len = h->n_in;
+    fa.n_frames = 1;
+    fa.mode = 0;
+    fa.p_begin = 0;
+    fa.p_count = 1;
+    fa.force_accept = 1;
+    fa.host_valid = 1;
+    fa.off_delta = int(window_ptr) - d.cp;
+    fa.force_dhat_p1 = lag_sync + 1;
+    fa.gain_lag_set = 1;
+    fa.gain_lag = lag_data;
+    fa.tsr = h->t_tsr + size_t(row) * 4;
+    fa.H = h->t_H + size_t(row) * N;
+    fa.gain = h->t_gain + size_t(row) * d.Kd;
+    fa.htime = h->t_imp + size_t(row) * N;
+    fa.esf = h->t_esf + size_t(row) * d.MM;
+    fa.yscratch = h->s_ysc;
+    HIP_TRY(launch_rx_sync(d, fa, h->stream));
+    return OFDM_OK;
+}
+
+int ofdm_trk_demod(ofdm_trk* h, int32_t n_sync, const int64_t* h_ptr, const uint8_t* h_guard, float* h_last, int32_t* last_row) {
+    if (!h || n_sync < 0 || (n_sync > 0 && (!h_ptr || !h_guard))) return fail(OFDM_ERR_INVALID, "ofdm_trk_demod: bad argument");
+    if (last_row) *last_row = -1;
+    if (n_sync == 0) return OFDM_OK;
+    if (n_sync > h->cfg.rows_sync) return fail(OFDM_ERR_INDEX, "%d syncs, %d rows", n_sync, h->cfg.rows_sync);
+    const RxDev& d = h->dev;
+    const int D = d.D, Kd = d.Kd;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<int> tsr(size_t(n_sync) * 4, 0);
+    int last = -1;
+    for (int p = 0; p < n_sync; ++p) {
+        tsr[size_t(p) * 4 + 0] = int(h_ptr[p]);
+        tsr[size_t(p) * 4 + 3] = h_guard[p] ? 1 : 0;
+        if (!h_guard[p]) continue;
+        if (p * D + D - 1 >= h->cfg.rows_data)
+            return fail(OFDM_ERR_INDEX, "est_data_freq has %d rows, sync %d needs row %d (the reference raises IndexError)",
+                        h->cfg.rows_data, p, p * D + D - 1);
+        if (h_ptr[p] + int64_t(D) * d.L >= h->n_in)                  // the last data slice of the pattern is empty
+            return fail(OFDM_ERR_SHAPE, "data window of sync %d starts past the buffer (the reference raises ValueError)", p);
+        last = p * D + D - 1;
+    }
+    HIP_TRY(hipMemcpyAsync(h->t_tsr, tsr.data(), tsr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    DemodArgs da{};
+    da.iq = h->d_in;
+    da.frame_stride = 0;
+    da.frame_len = h->n_in;
+    da.n_frames = n_sync;
+    da.tsr = h->t_tsr;
+    da.gain = h->t_gain;
+    da.eq = h->t_edf;
+    da.bits = nullptr;
+    da.bits_mode = 0;
+    da.mod = 2;
+    da.n_dsym = D;
+    da.spc = 0;
+    da.chunks_per_frame = 0;
+    da.row_stride_pat = D;
+    da.rows_per_frame = D;
+    da.zero_skipped = 0;
+    da.host_guard = 1;
+    HIP_TRY(launch_rx_demod(d, da, h->stream));
+    HIP_TRY(launch_row_renorm(h->t_edf, Kd, D, n_sync, h->t_tsr, h->stream));
+    if (h_last && last >= 0)
+        HIP_TRY(hipMemcpyAsync(h_last, h->t_edf + size_t(last) * Kd, size_t(Kd) * sizeof(cf), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // tsr (host vector) must stay alive until the copy has run
+    if (last_row) *last_row = last;
+    return OFDM_OK;
+}
+
+int ofdm_trk_get_state(ofdm_trk* h, float* h_chan_freq, float* h_chan_impulse, float* h_synch_freq, float* h_data_freq) {
+    if (!h) return fail(OFDM_ERR_INVALID, "ofdm_trk_get_state: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const RxDev& d = h->dev;
+    const size_t RS = size_t(h->cfg.rows_sync), RD = size_t(h->cfg.rows_data);
+    if (h_chan_freq) HIP_TRY(hipMemcpy(h_chan_freq, h->t_H, RS * d.nfft * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_chan_impulse) HIP_TRY(hipMemcpy(h_chan_impulse, h->t_imp, RS * d.nfft * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_synch_freq) HIP_TRY(hipMemcpy(h_synch_freq, h->t_esf, RS * d.Ks * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_data_freq && RD > 0) HIP_TRY(hipMemcpy(h_data_freq, h->t_edf, RD * d.Kd * sizeof(cf), hipMemcpyDeviceToHost));
     return OFDM_OK;
 }
 

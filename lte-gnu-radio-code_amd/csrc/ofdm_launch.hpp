@@ -27,6 +27,7 @@ struct DemodArgs {
     int variant;             // kernel tuning variant (0 = default)
     unsigned* stamps;        // diagnostic variant 9: [workgroups][waves][8] phase cycle sums, or null
     const cf* rot;           // per-sample rotator e^{j 2pi fo n/fs} [nfft] applied to every window (CFO receiver), or null
+    int host_guard;          // 1: a frame is demodulated iff tsr[frame][3] != 0 (the host applied the reference's own guard)
 };
 
 // ---- RX sync search + LS estimate (reference: SynchAndChanEst.py:143-219, "Loop A") -----------
@@ -51,6 +52,10 @@ struct SyncArgs {
     int* trial_d;            // mode 1: [n_rot*p_count] argmax lag
     const cf* rot;           // carrier-offset rotators [n_rot][nfft] (mode 1) / the one rotator of the finalize (mode 0), or null
     int n_rot;               // mode 1: candidates per trial (0 or 1 = plain)
+    int off_delta;           // added to the window start P*stride + cp (+L*LL); 0 = the reference layout of SynchAndChanEst
+    int host_valid;          // 1: the host already applied the block's own window-validity rule
+    int gain_lag_set;        // 1: the data gains are de-rotated with gain_lag instead of the trial's lag (may be negative)
+    int gain_lag;
     int force_dhat_p1;       // mode 0: lag+1 that replaces the trial's own arg-max lag (SynchEstAndFO.py:285,300); 0 = off
 };
 
@@ -97,6 +102,8 @@ hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s);
 hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s);
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s);
 // out[row][i] = mean_SF( in[row][SF + i*dsss] * conj(code[SF]) ), i < n_spread  (SynchEstFOAndDSSS.py:391-399)
+// rows visited in order; row r of frame f = f*D + n is divided by sqrt(mean |row f|^2) (SynchronizeAndEstimate.py:431-434)
+hipError_t launch_row_renorm(cf* eq, int Kd, int D, int n_frames, const int* tsr, hipStream_t s);
 hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out, hipStream_t s);
 hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s);
 hipError_t launch_channel(const ChanArgs& a, hipStream_t s);

@@ -178,7 +178,7 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false, bool HG = false>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
 
     const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
     const int tsr0 = a.tsr[frame * 4 + 0];
+    const bool frame_on = HG ? (a.tsr[frame * 4 + 3] != 0) : true;     // host-applied guard (tracker receiver)
     // L2IN (experiment only, wrong results): every workgroup reads frame (blockIdx % 8) -> the input stays cache-resident
     const cf* frame_iq = a.iq + int64_t(L2IN ? (blockIdx.x & 7) : frame) * a.frame_stride;
 
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         sy.valid = active && it < n_iter && ds < ds1;
         const int p = ds / D, n_ = ds - p * D;
         const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
-        sy.compute = sy.valid && (pat_ptr + N - 1 <= a.frame_len);
+        sy.compute = sy.valid && (HG ? frame_on : (pat_ptr + N - 1 <= a.frame_len));
         sy.start = pat_ptr + int64_t(L) * n_;
         sy.orow = int64_t(frame) * a.rows_per_frame + (p * a.row_stride_pat + n_);
         return sy;
@@ -444,6 +445,11 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     size_t lds = DG::lds_bytes(rx.Kd, true);
     if (a.variant >= 100) lds += size_t(a.variant - 100) * 1024;   // occupancy experiment: pad the LDS request by (variant-100) KiB
     const int bmode = a.bits ? a.bits_mode : 0;
+    if (a.host_guard) {             // tracker receiver: equalised symbols only, frames enabled by the host
+        if (bmode != 0 || a.rot) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, true, false, true, false, true, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+        return hipGetLastError();
+    }
     if (a.rot) {                    // CFO receiver: equalised symbols only
         if (bmode != 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, true, false, true, false, true, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);

@@ -22,7 +22,7 @@ template <int N>
 __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, int64_t frame_len, bool active,
                                            int Ptrial, cf* lds, float* red, const LaneTwiddles<N>& tw, const cf* w1tab, int t,
                                            cf (&Z)[Plan<N>::P], cf& zdup, float& p_est, float& m, int& dhat,
-                                           cf* yscratch, const cf* rot = nullptr) {
+                                           cf* yscratch, const cf* rot = nullptr, int off = 0) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     int* redi = reinterpret_cast<int*>(red) + 8;
@@ -31,7 +31,7 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
     zdup = cf{0.f, 0.f};
     float psum = 0.f;
     for (int LL = 0; LL < rx.S; ++LL) {
-        const int64_t w0 = int64_t(rx.L) * LL + int64_t(Ptrial) * rx.stride + rx.cp;   // :146
+        const int64_t w0 = int64_t(rx.L) * LL + int64_t(Ptrial) * rx.stride + rx.cp + off;   // :146
         cf v[P];
 #pragma unroll
         for (int n0 = 0; n0 < P; ++n0) {
@@ -131,12 +131,12 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
         const int cand = active ? int(unit / a.p_count) : 0;            // candidate-major: unit = cand * p_count + w
         const int Ptrial = a.p_begin + int(unit % a.p_count);
         const cf* rot = a.rot ? a.rot + int64_t(cand) * N : nullptr;
-        const bool valid = active && (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);  // :144
+        const bool valid = active && (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);  // :144
         cf Z[P];
         cf zdup;
         float p_est, m;
         int dhat;
-        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr, rot);
+        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr, rot, a.off_delta);
         if (active && t == 0) {
             a.trial_m[unit] = valid ? m : -1.f;
             a.trial_d[unit] = valid ? dhat : 0;
@@ -161,9 +161,9 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
         for (int it = 0;; ++it) {
             const int Ptrial = a.p_begin + it;
             const bool valid = active && (a.p_count <= 0 || it < a.p_count) &&
-                               (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+                               (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
             if (!valid) break;
-            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc, a.rot);
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc, a.rot, a.off_delta);
             if (a.force_dhat_p1 > 0) dhats = a.force_dhat_p1 - 1;
             if (a.force_accept || ms > rx.gate_mm) {                                    // :166
                 found = true;
@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
         for (int it = 0;; ++it) {
             const int Ptrial = a.p_begin + it;
             const bool valid = active && !found && (a.p_count <= 0 || it < a.p_count) &&
-                               (int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+                               (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
             if (!__syncthreads_or(valid ? 1 : 0)) break;
             cf Z[P];
             cf zdup;
             float p_est, m;
             int dhat;
-            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc, a.rot);
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc, a.rot, a.off_delta);
             if (a.force_dhat_p1 > 0) dhat = a.force_dhat_p1 - 1;
             if (valid && (a.force_accept || m > rx.gate_mm)) {                          // :166
                 found = true;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
     // ---- finalize (:171-218): LS estimate on the sync bins, equaliser gains, channel impulse response
     if (active && t == 0) {
         int* o = a.tsr + int64_t(frame) * 4;
-        o[0] = found ? Phit * rx.stride + rx.cp : 0;                                    // :173
+        o[0] = found ? Phit * rx.stride + rx.cp + a.off_delta : 0;                      // :173
         o[1] = found ? dhats : 0;                                                        // :174
         o[2] = found ? int(ms) : 0;                                                      // :175
         o[3] = found ? 1 : 0;
@@ -266,7 +266,8 @@ __global__ void __launch_bounds__(Plan<N>::WG) rx_sync_kernel(RxDev rx, SyncArgs
             }
             // data-bin gain: conj(Hd)/(|Hd|^2 + 1/SNR_lin) (:242-246) folded with the lag de-rotation (:237-240)
             const cf Hg = a.H_for_gain ? a.H_for_gain[int64_t(frame) * N + k] : Hk;
-            const cf gk = cmul(cscale(cconj(Hg), 1.f / (cnorm2(Hg) + rx.inv_snr_data)), rot);
+            const cf rot_g = a.gain_lag_set ? cconj(rx.tw[(a.gain_lag * k) & (N - 1)]) : rot;
+            const cf gk = cmul(cscale(cconj(Hg), 1.f / (cnorm2(Hg) + rx.inv_snr_data)), rot_g);
             int id_;
             if (bin_neg(k, Kd, N, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
             if (bin_pos(k, Kd, id_)) a.gain[int64_t(frame) * Kd + id_] = gk;
@@ -447,6 +448,31 @@ __global__ void __launch_bounds__(256) demap_soft_qam_kernel(DemapArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ row renormalisation
+// SynchronizeAndEstimate.py:431-434: after row r = f*D + n has been equalised it is divided by sqrt(mean |row f|^2) -- row f,
+// not row r -- in loop order, so row f already carries its own final scaling (f <= r; f == r only for row 0).
+__global__ void __launch_bounds__(256) row_renorm_kernel(cf* eq, int Kd, int D, int n_frames, const int* tsr) {
+    __shared__ float sh[256];
+    for (int f = 0; f < n_frames; ++f) {
+        if (tsr[f * 4 + 3] == 0) continue;                       // guard failed: row untouched
+        for (int n = 0; n < D; ++n) {
+            const int r = f * D + n;
+            float acc = 0.f;
+            for (int i = threadIdx.x; i < Kd; i += blockDim.x) acc += cnorm2(eq[int64_t(f) * Kd + i]);
+            sh[threadIdx.x] = acc;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+                __syncthreads();
+            }
+            const float inv = 1.f / sqrtf(sh[0] / float(Kd));
+            __syncthreads();
+            for (int i = threadIdx.x; i < Kd; i += blockDim.x) eq[int64_t(r) * Kd + i] = cscale(eq[int64_t(r) * Kd + i], inv);
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ DSSS despreading
 __global__ void despread_kernel(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -503,6 +529,12 @@ size_t rx_lds_bytes(int nfft) {
     }
 #undef CALL
     return 0;
+}
+
+hipError_t launch_row_renorm(cf* eq, int Kd, int D, int n_frames, const int* tsr, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(row_renorm_kernel, dim3(1), dim3(256), 0, s, eq, Kd, D, n_frames, tsr);
+    return hipGetLastError();
 }
 
 hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out, hipStream_t s) {

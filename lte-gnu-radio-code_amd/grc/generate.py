@@ -53,6 +53,9 @@ BLOCKS = [
                  ("file_name_cest", "Var: Chan Est -- File Name", "string"), ("diagnostics", "Diagnostics", "int")],
          make_args=["num_ofdm_symb", "nfft", "cp_len", "num_synch_bins", "synch_dat", "num_data_bins", "SNR", "directory_name",
                     "file_name_cest", "diagnostics"], inputs=CPLX_IN, outputs=CPLX_IN),
+    dict(id="OFDMReceiver_SynchronizeAndEstimate", label="SynchronizeAndEstimate (MI355X)", category="[OFDMReceiver]",
+         module="OFDMReceiver", cls="SynchronizeAndEstimate", params=[("case", "Case", "int")], make_args=["case"],
+         inputs=CPLX_IN, outputs=CPLX_IN),
     dict(id="OFDMReceiver_SynchEstAndFO", label="SynchEstAndFO (MI355X)", category="[OFDMReceiver]", module="OFDMReceiver",
          cls="SynchEstAndFO",
          params=[("case", "Case Number", "int"), ("fo_range", "F Offset Range", "raw"), ("directory_name", "Directory Path", "string"),

@@ -63,6 +63,12 @@ class FoReport(C.Structure):
                 ("n_data_items", C.c_int64)]
 
 
+class TrkCfg(C.Structure):
+    _fields_ = [("nfft", C.c_int32), ("cp_len", C.c_int32), ("num_synch_bins", C.c_int32), ("num_data_bins", C.c_int32),
+                ("synch_D", C.c_int32), ("rows_sync", C.c_int32), ("rows_data", C.c_int32), ("zc_root", C.c_int32),
+                ("snr", C.c_double), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
 FO_MAX_SYNC = 100
 
 # name -> (restype, argtypes): exactly the prototypes of include/ofdm_mi355x.h
@@ -95,6 +101,13 @@ PROTOTYPES = {
     "ofdm_fo_work": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(FoReport)]),
     "ofdm_fo_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofdm_fo_get_despread": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ofdm_trk_create": (C.c_int, [C.POINTER(TrkCfg), C.POINTER(C.c_void_p)]),
+    "ofdm_trk_destroy": (C.c_int, [C.c_void_p]),
+    "ofdm_trk_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "ofdm_trk_trials": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ofdm_trk_accept": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    "ofdm_trk_demod": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "ofdm_trk_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofdm_tx_create": (C.c_int, [C.POINTER(TxCfg), C.POINTER(C.c_void_p)]),
     "ofdm_tx_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_tx_modulate_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,

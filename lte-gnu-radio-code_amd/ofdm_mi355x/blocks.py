@@ -16,7 +16,7 @@ import pickle
 import numpy as np
 
 from . import _lib
-from .engine import DeviceBuffer, FoEngine, RxEngine, bins_p, zadoff_chu
+from .engine import DeviceBuffer, FoEngine, RxEngine, TrkEngine, bins_p, zadoff_chu
 from .gr_compat import sync_block
 from .safe_pickle import load_ndarray
 
@@ -322,6 +322,175 @@ class SynchEstFOAndDSSS(SynchEstAndFO):
     @property
     def est_data_freq_d(self):
         return self._engine.despread().astype(complex)
+
+
+# SDR_profile of SynchronizeAndEstimate (LEGACY/gr-ofdm-rx/python/SynchronizeAndEstimate.py:33-60), the fields the block uses
+_TRACKER_PROFILES = {
+    0: dict(system_scenario='4G5GSISO-TU', diagnostic=1, wireless_channel='Fading', channel_band=0.97 * 960e3, bin_spacing=15e3,
+            channel_profile='LTE-TU', CP_type='Normal', num_ant_txrx=1, param_est='Estimated', MIMO_method='SpMult', SNR=100,
+            ebno_db=[100] * 9, num_symbols=[48] + [1000] * 8, stream_size=1),
+    1: dict(system_scenario='WIFIMIMOSM-A', diagnostic=0, wireless_channel='Fading', channel_band=0.9 * 20e6, bin_spacing=312.5e3,
+            channel_profile='Indoor A', CP_type='Extended', num_ant_txrx=2, param_est='Ideal', MIMO_method='SpMult', SNR=50,
+            ebno_db=[6, 7, 8, 9, 10, 14, 16, 20, 24], num_symbols=[10] * 9, stream_size=2),
+}
+
+
+class SynchronizeAndEstimate(sync_block):
+    """OFDMReceiver.SynchronizeAndEstimate(case) -- acquisition by a strided ZC search, then a pointer tracker that follows
+    one sync symbol per [1,3] pattern (fixed advance for the first five, a least-squares line through the last five
+    (position + lag) observations afterwards), LS channel estimate per sync and three equalised data symbols per sync.
+
+    The pointer logic below is the reference's scalar control flow, statement for statement (:209-350); every array
+    computation -- windows, FFTs, lag correlation, channel estimate, equaliser, renormalisation -- runs on the GPU through
+    `TrkEngine`.  The regression uses `np.linalg.lstsq` exactly as the reference does (:341): the predicted pointer goes
+    through `ceil`, so the host keeps the same LAPACK routine rather than a closed form that could differ in the last bit.
+    """
+
+    def __init__(self, case):
+        sync_block.__init__(self, name="SynchronizeAndEstimate", in_sig=[np.complex64], out_sig=[np.complex64])
+        self.case = case
+        for k, v in _TRACKER_PROFILES[case].items():                              # KeyError for other cases, like :61
+            setattr(self, k, v)
+        self.synch_data = np.array([1, 3])                                        # :78
+        self.NFFT = int(2 ** (np.ceil(np.log2(round(self.channel_band / self.bin_spacing)))))      # :83
+        self.fs = self.bin_spacing * self.NFFT
+        self.len_CP = int(round(self.NFFT / 4))
+        num_bins1 = 4 * np.floor(np.floor(self.channel_band / self.bin_spacing) / 4)                # :87-90
+        all_bins = np.array(list(range(-int(num_bins1 / 2), 0)) + list(range(1, int(num_bins1 / 2) + 1)))
+        self.num_data_bins = len(all_bins)
+        self.used_bins_data = ((self.NFFT + all_bins) % self.NFFT).astype(int)                      # :102
+        n_pat = int(np.ceil(self.num_symbols[0] / sum(self.synch_data)))                            # :104
+        self.symbol_pattern = np.tile(np.concatenate((np.zeros(1), np.ones(3))), n_pat)
+        self._lmax_s, self._lmax_d = n_pat, 3 * n_pat                                               # :143-144
+        self.rx_buff_len = self.NFFT + self.len_CP
+        self.num_synch_bins = self.NFFT - 2
+        self.M = np.array([1, self.num_synch_bins])
+        self.MM = int(np.prod(self.M))
+        self.prime = 23
+        self.ZChu0 = zadoff_chu(self.MM, self.prime)                                                # :123-130
+        self.synch_ref = self.ZChu0
+        self.used_bins_synch = np.asarray(bins_p(self.num_synch_bins, self.NFFT)).astype(int)       # :134-136
+        if list(self.used_bins_data) != list(bins_p(self.num_data_bins, self.NFFT)):
+            raise ValueError("data bins are not the symmetric +-K/2 list the device kernels use")
+        self.time_synch_ref = np.zeros((self.num_ant_txrx, 250, 3))                                 # :179
+        self.corr_obs = None
+        self.stride_val = None
+        self.start_samp = None
+        self._engine = TrkEngine(self.NFFT, self.len_CP, self.num_synch_bins, self.num_data_bins, 3, self._lmax_s,
+                                 self._lmax_d if self.num_ant_txrx == 1 else 0, self.SNR, zc_root=self.prime, device=_device())
+
+    # -- arrays kept in HBM, fetched on access (antenna axis of length num_ant_txrx; only antenna 0 is ever written, :215)
+    def _ant(self, arr):
+        out = np.zeros((self.num_ant_txrx,) + arr.shape, dtype=complex)
+        out[0] = arr
+        return out
+
+    @property
+    def est_chan_freq_p(self):
+        return self._ant(self._engine.state()["chan_freq"])
+
+    @property
+    def est_chan_freq_n(self):
+        return self._ant(self._engine.state()["chan_freq"][:, self.used_bins_synch])
+
+    @property
+    def est_chan_impulse(self):
+        return self._ant(self._engine.state()["chan_impulse"])
+
+    @property
+    def est_synch_freq(self):
+        return self._ant(self._engine.state()["synch_freq"])
+
+    @property
+    def est_data_freq(self):
+        if self.num_ant_txrx != 1:
+            raise AttributeError("'SynchronizeAndEstimate' object has no attribute 'est_data_freq'")   # :160-165
+        return self._ant(self._engine.state()["data_freq"])
+
+    def work(self, input_items, output_items):
+        in0 = input_items[0]
+        out = output_items[0]
+        eng = self._engine
+        n_in = in0.shape[0]
+        N, cp, L, m = self.NFFT, self.len_CP, self.rx_buff_len, 0
+        eng.load(in0)
+        self.stride_val = np.ceil(cp / 2)                                         # :209
+        ptr_frame, b, xp = 0, 0, []
+        self.corr_obs = -1                                                        # :216
+        self.start_samp = (cp - 4) - 1                                            # :219
+        total_loops = int(np.ceil(n_in / self.stride_val))
+        ptr_adj, loop_count, sym_count = 0, 0, 0
+        tap_delay = 5
+        x = np.zeros(tap_delay)
+        ptr_synch0 = np.zeros(1000)
+        sd = int(sum(self.synch_data))
+        # acquisition windows (corr_obs == -1: ptr_adj is still 0) are independent: one batched launch
+        step, first = int(self.stride_val), int(self.start_samp)
+        n_acq = 0
+        while n_acq <= total_loops and N + (n_acq * step + first) < n_in:         # :240
+            n_acq += 1
+        acq_peak, acq_lag = eng.trials(first, step, n_acq)
+        memo = {}
+
+        def trial(ptr):
+            key = int(ptr)
+            if key not in memo:
+                pk, lg = eng.trials(key, 1, 1)
+                memo[key] = (float(pk[0]), int(lg[0]))
+            return memo[key]
+
+        while loop_count <= total_loops:                                          # :230
+            if self.corr_obs == -1:
+                ptr_frame = loop_count * self.stride_val + self.start_samp + ptr_adj
+            elif self.corr_obs < 5:
+                ptr_frame += sd * (N + cp)
+            else:
+                ptr_frame = (np.ceil(np.dot(xp[-1:], b) - cp / 4))[0]            # :237
+            if N + ptr_frame < n_in:                                              # :240
+                window_ptr = int(ptr_frame)
+                if self.corr_obs == -1:
+                    dmax, dmax_ind0 = float(acq_peak[loop_count]), int(acq_lag[loop_count])
+                else:
+                    if window_ptr < 0:
+                        raise IndexError("window pointer %d before the buffer" % window_ptr)
+                    dmax, dmax_ind0 = trial(window_ptr)
+                dmax_ind = dmax_ind0 - 1                                          # :275
+                if dmax > 0.5 * self.MM or self.corr_obs > -1:                    # :279
+                    if dmax_ind > np.ceil(0.75 * cp):                             # :281 pointer moves, window does not
+                        if self.corr_obs == -1:
+                            ptr_adj += np.ceil(0.5 * cp)
+                            ptr_frame = loop_count * self.stride_val + self.start_samp + ptr_adj
+                        elif self.corr_obs < 5:
+                            ptr_frame += np.ceil(0.5 * cp)
+                    time_synch_ind = self.time_synch_ref[m, max(self.corr_obs, 1), 0]            # :311
+                    if ptr_frame - time_synch_ind > (2 * cp + N) or self.corr_obs == -1:         # :313
+                        self.corr_obs += 1
+                        self.time_synch_ref[m, self.corr_obs] = [ptr_frame, dmax_ind, dmax]      # :316-318
+                        ptr_synch0[sym_count % tap_delay] = sum(self.time_synch_ref[m, self.corr_obs, 0:2])
+                        x[sym_count % tap_delay] = sym_count * sd
+                        sym_count += 1
+                        x2 = x[0:min(self.corr_obs, tap_delay)]
+                        x_plus = np.concatenate((x2, np.atleast_1d(sym_count * sd)))
+                        xp = np.zeros((len(x_plus), 2))
+                        xp[:, 0] = 1
+                        xp[:, 1] = x_plus
+                        if self.corr_obs > 3:                                     # :333-341
+                            y = ptr_synch0[0:min(tap_delay, self.corr_obs)]
+                            X = np.zeros((len(x2), 2))
+                            X[:, 0] = 1
+                            X[:, 1] = x2
+                            b = np.linalg.lstsq(X, y, rcond=-1)[0]
+                        # LS estimate on the device (:344-378); a lag of -1 selects the LAST phase column there
+                        eng.accept(self.corr_obs, window_ptr, dmax_ind if dmax_ind >= 0 else cp, dmax_ind)
+            loop_count += 1
+        if self.num_ant_txrx == 1:                                                # :397
+            n_sync = self.corr_obs + 1
+            ptrs = [int(self.time_synch_ref[m, p, 0]) for p in range(n_sync)]
+            guards = [bool(sum(self.time_synch_ref[m, p, :]) + N < n_in) for p in range(n_sync)]  # :401
+            last_row, last = eng.demod(ptrs, guards)
+            if last_row >= 0:
+                out[0:self.num_data_bins] = last                                  # :438-440
+        return len(output_items[0])
 
 
 def _load_iq_file(path: str) -> np.ndarray:

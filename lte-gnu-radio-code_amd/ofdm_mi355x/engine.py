@@ -232,6 +232,62 @@ class FoEngine:
             pass
 
 
+class TrkEngine:
+    """Device primitives of the regression-tracking receiver (reference: LEGACY/gr-ofdm-rx/python/SynchronizeAndEstimate.py):
+    strided / single sync trials, LS estimate per accepted sync, data stage.  The sequential pointer logic lives in the
+    block mirror (`blocks.SynchronizeAndEstimate`)."""
+
+    def __init__(self, nfft, cp_len, num_synch_bins, num_data_bins, synch_D, rows_sync, rows_data, snr, zc_root=23, device=0):
+        self.lib = _lib.load()
+        self.cfg = _lib.TrkCfg(int(nfft), int(cp_len), int(num_synch_bins), int(num_data_bins), int(synch_D), int(rows_sync),
+                               int(rows_data), int(zc_root), float(snr), int(device), 0)
+        h = C.c_void_p()
+        check(self.lib.ofdm_trk_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+
+    def load(self, in0: np.ndarray):
+        in0 = np.ascontiguousarray(in0, dtype=np.complex64)
+        check(self.lib.ofdm_trk_load(self._h, ptr(in0), in0.size))
+
+    def trials(self, first_ptr: int, step: int, count: int):
+        peak = np.zeros(max(count, 1), np.float32)
+        lag = np.zeros(max(count, 1), np.int32)
+        check(self.lib.ofdm_trk_trials(self._h, int(first_ptr), int(step), int(count), ptr(peak), ptr(lag)))
+        return peak[:count], lag[:count]
+
+    def accept(self, row: int, window_ptr: int, lag_sync: int, lag_data: int):
+        check(self.lib.ofdm_trk_accept(self._h, int(row), int(window_ptr), int(lag_sync), int(lag_data)))
+
+    def demod(self, ptrs, guards):
+        n = len(ptrs)
+        p = np.ascontiguousarray(ptrs, dtype=np.int64)
+        g = np.ascontiguousarray(guards, dtype=np.uint8)
+        last = np.zeros(self.cfg.num_data_bins, np.complex64)
+        row = C.c_int32(-1)
+        check(self.lib.ofdm_trk_demod(self._h, n, ptr(p) if n else None, ptr(g) if n else None, ptr(last), C.byref(row)))
+        return int(row.value), last
+
+    def state(self):
+        c = self.cfg
+        H = np.zeros((c.rows_sync, c.nfft), np.complex64)
+        imp = np.zeros((c.rows_sync, c.nfft), np.complex64)
+        esf = np.zeros((c.rows_sync, c.num_synch_bins), np.complex64)
+        edf = np.zeros((max(c.rows_data, 0), c.num_data_bins), np.complex64)
+        check(self.lib.ofdm_trk_get_state(self._h, ptr(H), ptr(imp), ptr(esf), ptr(edf) if c.rows_data > 0 else None))
+        return dict(chan_freq=H, chan_impulse=imp, synch_freq=esf, data_freq=edf)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ofdm_trk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TxEngine:
     """Transmit chain handle (bit map, resource grid + ZC sync symbols, IFFT + CP + normalise) and channel."""
 
