@@ -27,7 +27,11 @@ CASES = [
     ("fade", 0, 48, 21, True, 0.0),
     ("noisy", 0, 44, 2, True, 0.02),
     ("mimo_cfg", 1, 12, 5, True, 0.0),
+    # the reference's own TX fixture (LEGACY/gr-ofdm-tx/python/tx_data_0.pckl: 48 symbols x 80 samples, [1,3] pattern, ZC root 23),
+    # read with the non-executing ndarray-pickle parser; no bit fixture exists for it
+    ("txdata0", 0, None, 0, False, 0.0),
 ]
+FIXTURE = "/root/reference/GNU-Radio-Repositories/LEGACY/gr-ofdm-tx/python/tx_data_0.pckl"
 
 
 def make_input(n_sym, lead, fading, sigma, seed):
@@ -48,7 +52,14 @@ def main():
     out = {}
     warnings.simplefilter("ignore")          # FutureWarning of np.linalg.lstsq's default rcond
     for i, (tag, case, n_sym, lead, fading, sigma) in enumerate(CASES):
-        iq, bits = make_input(n_sym, lead, fading, sigma, 700 + i)
+        if n_sym is None:
+            import sys
+            sys.path.insert(0, os.path.join(G.ROOT, "lte-gnu-radio-code_amd"))
+            from ofdm_mi355x.safe_pickle import load_ndarray
+            iq = np.concatenate([load_ndarray(FIXTURE)[0], np.zeros(40)]).astype(np.complex64)
+            bits = np.zeros(0, np.uint8)
+        else:
+            iq, bits = make_input(n_sym, lead, fading, sigma, 700 + i)
         blk = cls(case)
         out[tag + "_iq"] = iq
         out[tag + "_bits"] = bits.astype(np.uint8)

@@ -249,3 +249,22 @@ def test_stream_block_call_sequence_state(om, golden):
         if i > 0:
             assert relerr(blk.est_chan_freq_P[1], o.est_chan_freq_P[1]) < TOL
             assert relerr(blk.est_chan_time[1], o.est_chan_time[1]) < TOL
+
+
+def test_stream_block_on_second_reference_fixture(om, golden):
+    """LEGACY/gr-ofdm-tx/python/tx_data_0.pckl (48 symbols) through the block vs the recorded reference run, two calls."""
+    ref = golden("ref_rx_txdata0.npz")
+    iq = ref["iq"]
+    blk = _block(48, 64, 16, 60)
+    for call in (1, 2):
+        out = np.zeros(len(iq), np.complex64)
+        assert blk.work([iq], [out]) == len(iq)
+        k = "call%d_" % call
+        _check_tsr(blk.time_synch_ref, ref[k + "tsr"])
+        # call 2: the estimate of the later detection lives in row 1 (corr_obs == 1), the data equaliser keeps row 0
+        assert relerr(blk.est_chan_freq_P[0], ref[k + "H"]) < TOL
+        assert relerr(blk.est_chan_time[0], ref[k + "htime"]) < TOL
+        assert relerr(blk.est_data_freq, ref[k + "edf"]) < TOL
+        assert relerr(blk.est_synch_freq[0], ref[k + "esf"]) < TOL
+        assert relerr(blk.eq_gain, ref[k + "eq_gain"]) < TOL
+        assert relerr(out, ref[k + "out"]) < TOL or not ref[k + "out"].any()

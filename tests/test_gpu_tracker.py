@@ -33,7 +33,7 @@ def _compare(blk, tsr, Hp, Hn, imp, esf, edf, out, ref_out):
         assert not out.any() and not ref_out.any()
 
 
-@pytest.mark.parametrize("tag", ["clean", "fade", "noisy", "mimo_cfg"])
+@pytest.mark.parametrize("tag", ["clean", "fade", "noisy", "mimo_cfg", "txdata0"])
 def test_tracker_block_on_reference_runs(golden, tag):
     g = golden("ref_tracker.npz")
     case = int(g[tag + "_case"][0])
@@ -47,7 +47,7 @@ def test_tracker_block_on_reference_runs(golden, tag):
         assert blk.corr_obs == int(g[k + "corr_obs"][0])
         _compare(blk, g[k + "tsr"], g[k + "Hp"], g[k + "Hn"], g[k + "imp"], g[k + "esf"],
                  g[k + "edf"] if case == 0 else None, out, g[k + "out"])
-    if case == 0:
+    if case == 0 and tag != "txdata0":
         blk2 = _block(0)
         blk2.work([iq], [np.zeros(len(iq), np.complex64)])
         n_sync = blk2.corr_obs + 1

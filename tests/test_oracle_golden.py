@@ -174,3 +174,23 @@ def test_bins_and_zc_edge_cases():
     zc_odd = orc.zadoff_chu(63, 23)
     assert np.allclose(np.abs(zc_even), 1) and np.allclose(np.abs(zc_odd), 1)
     assert abs(zc_odd[1] - np.exp(-1j * 2 * np.pi / 63 * 23 * 1.0)) < 1e-15
+
+
+def test_rx_matches_reference_run_on_second_fixture(golden):
+    """The reference's other data fixture (LEGACY/gr-ofdm-tx/python/tx_data_0.pckl, 48 symbols) through the reference
+    gr-utsa_ofdm block, two calls (tests/golden/gen_golden_txdata0.py)."""
+    ref = golden("ref_rx_txdata0.npz")
+    iq = ref["iq"]
+    rx = orc.RxOracle(48, 64, 16, 62, [1, 3], 60, 100, 0.7)
+    for call in (1, 2):
+        out = np.zeros(len(iq), np.complex64)
+        rx.work(iq, out)
+        k = "call%d_" % call
+        assert np.array_equal(rx.time_synch_ref, ref[k + "tsr"])
+        assert relerr(rx.est_chan_freq_P[0], ref[k + "H"]) < 1e-12
+        assert relerr(rx.est_chan_time[0], ref[k + "htime"]) < 1e-12
+        assert relerr(rx.est_data_freq, ref[k + "edf"]) < 1e-12
+        assert relerr(rx.est_synch_freq[0], ref[k + "esf"]) < 1e-12
+        assert relerr(rx.eq_gain, ref[k + "eq_gain"]) < 1e-12
+        assert relerr(out, ref[k + "out"]) < 1e-6 or not ref[k + "out"].any()
+    assert list(ref["call1_tsr"]) == [16.0, 0.0, 61.0] and list(ref["call2_tsr"]) == [320.0, 16.0, 61.0]

@@ -9,7 +9,7 @@ from conftest import relerr
 from oracle import ofdm_oracle as orc
 
 
-@pytest.mark.parametrize("tag", ["clean", "fade", "noisy", "mimo_cfg"])
+@pytest.mark.parametrize("tag", ["clean", "fade", "noisy", "mimo_cfg", "txdata0"])
 def test_tracker_oracle_matches_reference_runs(golden, tag):
     g = golden("ref_tracker.npz")
     case = int(g[tag + "_case"][0])
@@ -32,7 +32,13 @@ def test_tracker_oracle_matches_reference_runs(golden, tag):
             assert relerr(out, g[k + "out"]) < 1e-6
         else:
             assert not out.any() and not g[k + "out"].any()
-    if case == 0:
+    if tag == "txdata0":
+        # the reference's own fixture: 12 syncs, every peak = MM = 62 (a noiseless ZC symbol), 320 samples apart until the
+        # regression takes over
+        t = g["txdata0_call1_tsr"][0]
+        assert int(g["txdata0_call1_corr_obs"][0]) == 11 and np.allclose(t[:12, 2], 62.0, atol=1e-6)
+        assert np.array_equal(t[:6, 0], 11 + 320 * np.arange(6))
+    elif case == 0:
         # call 1 found every pattern: its rows de-map to the transmitted bits (checked on the recorded reference rows)
         edf = g[tag + "_call1_edf"][0]
         n_sync = int(g[tag + "_call1_corr_obs"][0]) + 1
