@@ -190,7 +190,21 @@ __global__ void __launch_bounds__(256) channel_kernel(ChanArgs a) {
 __global__ void __launch_bounds__(256) probe_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n16, int mode,
                                                      int sym_in16, int gap16, int sym_out16, int64_t n_sym) {
     if (mode == 0) {
-        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += int64_t(gridDim.x) * blockDim.x) out[i] = in[i];
+        // four independent non-temporal 16 B loads in flight per lane, 16 Ki workgroups: the best plain-copy shape found on
+        // these chips by tools/ubench/copy_bw.hip (5.0-5.4 TB/s; one load per iteration on 4 Ki workgroups gives 4.5-4.7)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* src = reinterpret_cast<const f4*>(in);
+        f4* dst = reinterpret_cast<f4*>(out);
+        const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+        int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+        }
+        for (; i < n16; i += stride) dst[i] = src[i];
     } else {
         for (int64_t s = blockIdx.x; s < n_sym; s += gridDim.x) {
             const float4* src = in + s * (sym_in16 + gap16) + gap16;
@@ -207,7 +221,7 @@ __global__ void __launch_bounds__(256) probe_kernel(const float4* __restrict__ i
 
 hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
                         hipStream_t s) {
-    const unsigned grid = mode == 0 ? 256 * 16 : unsigned(std::min<int64_t>(n_sym, 256 * 32));
+    const unsigned grid = mode == 0 ? 256 * 64 : unsigned(std::min<int64_t>(n_sym, 256 * 32));
     hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), 0, s, static_cast<const float4*>(in), static_cast<float4*>(out), n16, mode,
                        sym_in16, gap16, sym_out16, n_sym);
     return hipGetLastError();
