@@ -152,6 +152,10 @@ def main():
     else:
         torch.cuda.set_device(0)
     device = torch.cuda.current_device()
+    # Everything runs on ONE explicit torch stream.  torch's default stream has handle 0, which the C ABI reads as "use the
+    # handle's own (non-blocking) stream": kernels would then be unordered with torch's allocator, with torch copies and -- at
+    # N > 1 -- with RCCL, which orders itself against torch's CURRENT stream only.
+    torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     cfg = dict(CONFIGS[args.config])
     n_frames = args.frames or cfg["frames"]

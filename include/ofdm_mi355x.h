@@ -12,7 +12,8 @@
  *   - every function returns OFDM_OK (0) / a non-negative count, or a negative ofdm_status;
  *     ofdm_last_error() gives the message of the calling thread's last failure.
  *   - `d_` arguments are DEVICE pointers (HBM of the handle's GPU), `h_` arguments are HOST pointers.
- *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).  Batch entry
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own NON-BLOCKING stream; mind that
+ *     the legacy default stream also has handle 0, so it cannot be named here).  Batch entry
  *     points are asynchronous on that stream and allocate nothing.
  *   - a handle owns one HIP stream and its device tables; no global mutable state in the library,
  *     so different block instances (GNU Radio: one thread per block) may run concurrently.

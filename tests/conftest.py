@@ -15,6 +15,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The torch wheel carries its own HIP runtime next to the system one libofdm_mi355x.so links against.  Both coexist as long
+    # as torch initialises first (bench.py does); a torch.cuda call made AFTER the library has touched the GPU fails with "No HIP
+    # GPUs are available".  Tests that use torch for device memory therefore need it initialised before any other test runs.
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")

@@ -12,6 +12,7 @@ variants = [int(x) for x in sys.argv[1:]] or [0]
 cfg = dict(bench.CONFIGS[os.environ.get("KB_CONFIG", "cfg2")])
 n_frames = int(os.environ.get("KB_FRAMES", "2048"))
 torch.cuda.set_device(0)
+torch.cuda.set_stream(torch.cuda.Stream())   # a real stream handle (0 would mean the library's own stream)
 d_rx, _ = bench.build_inputs(torch, om, cfg, n_frames, 0, 1)
 N, cp, Kd, n_sym = cfg["nfft"], cfg["cp"], cfg["Kd"], cfg["n_sym"]
 fl = n_sym * (N + cp)
