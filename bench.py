@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-eq", action="store_true", help="do not write equalised symbols (bits only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step for all-gather overlap (N>1)")
+    ap.add_argument("--mod", default=None, choices=sorted(BPS), help="override the config's constellation (numerology sweep)")
     args = ap.parse_args()
 
     import torch
@@ -158,6 +159,9 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     cfg = dict(CONFIGS[args.config])
+    if args.mod:
+        cfg["name"] = cfg["name"].replace(cfg["mod"].replace("QAM", "-QAM"), args.mod.replace("QAM", "-QAM"))
+        cfg["mod"] = args.mod
     n_frames = args.frames or cfg["frames"]
     N, cp, Kd, mod, n_sym = cfg["nfft"], cfg["cp"], cfg["Kd"], cfg["mod"], cfg["n_sym"]
     L = N + cp

@@ -221,8 +221,10 @@ __global__ void __launch_bounds__(256) probe_kernel(const float4* __restrict__ i
 
 hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
                         hipStream_t s) {
+    const size_t lds = size_t(mode >> 4) * 1024;      // occupancy experiment: mode = base + 16 * KiB of (unused) dynamic LDS
+    mode &= 15;
     const unsigned grid = mode == 0 ? 256 * 64 : unsigned(std::min<int64_t>(n_sym, 256 * 32));
-    hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), 0, s, static_cast<const float4*>(in), static_cast<float4*>(out), n16, mode,
+    hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), lds, s, static_cast<const float4*>(in), static_cast<float4*>(out), n16, mode,
                        sym_in16, gap16, sym_out16, n_sym);
     return hipGetLastError();
 }
