@@ -156,6 +156,21 @@ OFDM_HD void load_twiddles(LaneTwiddles<N>& tw, const cf* __restrict__ table, in
     for (int k0 = 0; k0 < PL::R0; ++k0) tw.w0[k0] = table[(k0 * t) & (N - 1)];
 }
 
+// Compact form of the pass-0 twiddles (R0 == 16): only W^t, W^2t, W^4t, W^8t are held (8 VGPRs instead of 30); the other
+// eleven are products formed right where they are used (11 extra complex products per symbol, at most two temporaries live).
+template <int N>
+struct CompactTwiddles {
+    cf w1, w2, w4, w8;
+};
+
+template <int N>
+OFDM_HD void load_twiddles(CompactTwiddles<N>& tw, const cf* __restrict__ table, int t) {
+    tw.w1 = table[t & (N - 1)];
+    tw.w2 = table[(2 * t) & (N - 1)];
+    tw.w4 = table[(4 * t) & (N - 1)];
+    tw.w8 = table[(8 * t) & (N - 1)];
+}
+
 // entry e = n2*16 + k1 of the pass-1 table (3-pass plans: e < 16*RL)
 template <int N>
 OFDM_HD cf w1_entry(const cf* __restrict__ table, int e) {
@@ -163,6 +178,51 @@ OFDM_HD cf w1_entry(const cf* __restrict__ table, int e) {
 }
 
 // ------------------------------------------------------------------------------------------ passes
+// pass 0 with compact twiddles (same result up to the rounding of the twiddle products, ~2e-7 relative)
+template <int N>
+OFDM_HD void fft_pass0_store(cf (&v)[Plan<N>::P], cf* lds, const CompactTwiddles<N>& twc, int t) {
+    using PL = Plan<N>;
+    static_assert(PL::R0 == 16, "compact twiddles are for the radix-16 first pass");
+    dft_dif<16, 0, 1, PL::P>(v);
+    constexpr int row = PL::THREE ? (PL::T + 2) : (PL::RL + 1);
+    constexpr int R = 16;
+    CompactTwiddles<N> tw = twc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque copies: without this the products below are loop-invariant and hipcc hoists all eleven back into VGPRs
+    asm volatile("" : "+v"(tw.w1), "+v"(tw.w2), "+v"(tw.w4), "+v"(tw.w8));
+#endif
+#define OFDM_V(k) v[bitrev(k, R)]
+    cmul3(OFDM_V(1), tw.w1, OFDM_V(2), tw.w2, OFDM_V(4), tw.w4);
+    OFDM_V(8) = cmul(OFDM_V(8), tw.w8);
+    {
+        cf a = cmul(tw.w1, tw.w2);                 // W^3t
+        OFDM_V(3) = cmul(OFDM_V(3), a);
+        cf b = cmul(a, tw.w8);                     // W^11t
+        OFDM_V(11) = cmul(OFDM_V(11), b);
+        a = cmul(a, tw.w4);                        // W^7t
+        OFDM_V(7) = cmul(OFDM_V(7), a);
+        a = cmul(a, tw.w8);                        // W^15t
+        OFDM_V(15) = cmul(OFDM_V(15), a);
+        a = cmul(tw.w1, tw.w4);                    // W^5t
+        OFDM_V(5) = cmul(OFDM_V(5), a);
+        a = cmul(a, tw.w8);                        // W^13t
+        OFDM_V(13) = cmul(OFDM_V(13), a);
+        a = cmul(tw.w2, tw.w4);                    // W^6t
+        OFDM_V(6) = cmul(OFDM_V(6), a);
+        a = cmul(a, tw.w8);                        // W^14t
+        OFDM_V(14) = cmul(OFDM_V(14), a);
+        a = cmul(tw.w1, tw.w8);                    // W^9t
+        OFDM_V(9) = cmul(OFDM_V(9), a);
+        a = cmul(tw.w2, tw.w8);                    // W^10t
+        OFDM_V(10) = cmul(OFDM_V(10), a);
+        a = cmul(tw.w4, tw.w8);                    // W^12t
+        OFDM_V(12) = cmul(OFDM_V(12), a);
+    }
+#undef OFDM_V
+#pragma unroll
+    for (int k0 = 0; k0 < R; ++k0) lds[k0 * row + t] = v[bitrev(k0, R)];
+}
+
 // Each function is the work of ONE lane t (0..T-1) of one symbol; `lds` is that symbol's exchange
 // region (Plan<N>::LDS_ELEMS elements).  The caller puts a workgroup barrier between consecutive calls.
 

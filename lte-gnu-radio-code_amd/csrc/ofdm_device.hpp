@@ -130,8 +130,8 @@ __device__ __forceinline__ const cf* wg_init_w1(cf* smem, const cf* __restrict__
 // On return lane t holds bin k = (t + T*j) + NC*kl in v[out_slot<N>(j,kl)].
 // Contains 1 (2-pass) or 3 (3-pass) workgroup barriers; the symbol's LDS region may still be read by
 // other lanes on return, so the caller must barrier before overwriting it.
-template <int N>
-__device__ __forceinline__ void wg_fft(cf (&v)[Plan<N>::P], cf* lds, const LaneTwiddles<N>& tw, const cf* w1tab, int t) {
+template <int N, class TW>
+__device__ __forceinline__ void wg_fft(cf (&v)[Plan<N>::P], cf* lds, const TW& tw, const cf* w1tab, int t) {
     fft_pass0_store<N>(v, lds, tw, t);
     wg_barrier();
     if constexpr (Plan<N>::THREE) {

@@ -17,6 +17,8 @@
 // BMODE 0 = no bits, 1 = packed MSB-first, 2 = one bit per byte      } decision code has no runtime switches
 // MINW  __launch_bounds__ min waves per SIMD (register budget; 3 -> 168 VGPRs)
 #pragma once
+#include <type_traits>
+
 #include "ofdm_launch.hpp"
 
 namespace ofdm {
@@ -178,14 +180,16 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false, bool HG = false>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false, bool HG = false, bool CT = false>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
     constexpr int T = PL::T, P = PL::P, Q = P / 4, NS = DG::NS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int slot = tid / T;
+    // a slot spans whole wavefronts when T >= 64: everything derived from it (symbol bookkeeping, row pointers) is then
+    // wave-uniform, and saying so moves it from VGPRs / VALU to SGPRs / SALU
+    const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
     const int t = tid % T;
     cf* smem = reinterpret_cast<cf*>(smem_raw);
     cf* lds = smem + slot * WgLds<N>::STRIDE;
@@ -204,8 +208,8 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     const int ds1 = min(ds0 + a.spc, a.n_dsym);
     constexpr bool active = true;
 
-    LaneTwiddles<N> tw;
-    load_twiddles<N>(tw, rx.tw, t);
+    std::conditional_t<CT, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, rx.tw, t);
 
     const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
     const int tsr0 = a.tsr[frame * 4 + 0];
@@ -462,6 +466,8 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 5) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 6) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 7) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 8) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 4, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             return hipGetLastError();
         }
