@@ -260,8 +260,8 @@ int ofdm_trk_trials(ofdm_trk* h, int64_t first_ptr, int32_t step, int32_t count,
 int ofdm_trk_accept(ofdm_trk* h, int32_t row, int64_t window_ptr, int32_t lag_sync, int32_t lag_data);
 /* Data stage (:397-440) for syncs 0..n_sync-1: h_ptr[p] = time_synch_ref[p][0]; h_guard[p] != 0 iff :401 holds.  Rows
  * p*D+n of est_data_freq are equalised and renormalised in loop order; h_last[Kd] receives the last row processed (what
- * lands in out[0:Kd], :438-440), *last_row its index or -1.  A row past rows_data -> OFDM_ERR_INDEX; an empty data slice
- * -> OFDM_ERR_SHAPE (np.fft.fft raises ValueError); shorter slices are zero-padded like fft(x, N). */
+ * lands in out[0:Kd], :438-440), *last_row its index or -1.  A row past rows_data -> OFDM_ERR_INDEX; short and even empty
+ * data slices are zero-padded like np.fft.fft(x, N) does. */
 int ofdm_trk_demod(ofdm_trk* h, int32_t n_sync, const int64_t* h_ptr, const uint8_t* h_guard, float* h_last, int32_t* last_row);
 /* complex64 interleaved, any pointer may be NULL: h_chan_freq[rows_sync][nfft], h_chan_impulse[rows_sync][nfft],
  * h_synch_freq[rows_sync][Ks], h_data_freq[rows_data][Kd] */

@@ -610,21 +610,29 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
     fill_report();   // valid even if the call fails below, like the attributes the reference has already updated
 
     // ---------------- Loop B: data demod (:221-248)
+    // The reference works symbol by symbol and raises IndexError from the first row that does not exist (:248) AFTER having
+    // written every earlier row; the same rows are written here before the error is returned.  A window that starts past the
+    // buffer is not an error: np.fft.fft(x, nfft) zero-pads even an empty slice (:230), the row becomes 0 * inf = NaN there
+    // and here alike.
     const int64_t tsr0 = int64_t(h->tsr[0]);
     int64_t n_pat_loop = (n_unique + SD - 1) / SD;                           // range(n_unique)[::S+D]
-    int64_t p_ok = 0;
-    for (int64_t p = 0; p < n_pat_loop; ++p) {
+    int64_t n_dsym_run = 0;                                                  // data symbols the reference gets through
+    int loop_b_err = OFDM_OK;
+    char loop_b_msg[160] = "";
+    for (int64_t p = 0; p < n_pat_loop && loop_b_err == OFDM_OK; ++p) {
         const int64_t ptr = tsr0 + int64_t(S) * L * (p * SD + 1);            // :222
-        if (ptr + N - 1 <= n_in) {                                           // :223
-            if (ptr >= n_in)   // an empty slice: np.fft.fft raises "Invalid number of FFT data points (0)"
-                return fail(OFDM_ERR_SHAPE, "data window of pattern %lld starts past the buffer (the reference raises ValueError)", (long long)p);
-            if (p * SD + D - 1 >= h->cfg.num_ofdm_symb)
-                return fail(OFDM_ERR_INDEX, "est_data_freq has %d rows, pattern %lld needs row %lld (the reference raises IndexError)",
-                            h->cfg.num_ofdm_symb, (long long)p, (long long)(p * SD + D - 1));
-            p_ok = p + 1;
+        if (!(ptr + N - 1 <= n_in)) continue;                                // :223 (monotonic: later patterns fail too)
+        for (int n = 0; n < D; ++n) {
+            if (p * SD + n >= h->cfg.num_ofdm_symb) {
+                loop_b_err = OFDM_ERR_INDEX;
+                snprintf(loop_b_msg, sizeof loop_b_msg, "est_data_freq has %d rows, pattern %lld needs row %lld (the reference raises IndexError)",
+                         h->cfg.num_ofdm_symb, (long long)p, (long long)(p * SD + n));
+                break;
+            }
+            n_dsym_run = p * D + n + 1;
         }
     }
-    if (p_ok > 0) {
+    if (n_dsym_run > 0) {
         DemodArgs da{};
         da.iq = h->d_in;
         da.frame_stride = n_in;
@@ -636,7 +644,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         da.bits = nullptr;
         da.bits_mode = 0;
         da.mod = d.bps;
-        da.n_dsym = int(p_ok * D);
+        da.n_dsym = int(n_dsym_run);
         da.spc = 0;
         da.chunks_per_frame = 0;
         da.row_stride_pat = SD;
@@ -644,6 +652,10 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         da.zero_skipped = 0;
         da.variant = h->variant;
         HIP_TRY(launch_rx_demod(d, da, s));
+    }
+    if (loop_b_err != OFDM_OK) {
+        HIP_TRY(hipStreamSynchronize(s));
+        return fail(loop_b_err, "%s", loop_b_msg);
     }
 
     // ---------------- output packing (:249-262)
@@ -1192,8 +1204,6 @@ int ofdm_trk_demod(ofdm_trk* h, int32_t n_sync, const int64_t* h_ptr, const uint
         if (p * D + D - 1 >= h->cfg.rows_data)
             return fail(OFDM_ERR_INDEX, "est_data_freq has %d rows, sync %d needs row %d (the reference raises IndexError)",
                         h->cfg.rows_data, p, p * D + D - 1);
-        if (h_ptr[p] + int64_t(D) * d.L >= h->n_in)                  // the last data slice of the pattern is empty
-            return fail(OFDM_ERR_SHAPE, "data window of sync %d starts past the buffer (the reference raises ValueError)", p);
         last = p * D + D - 1;
     }
     HIP_TRY(hipMemcpyAsync(h->t_tsr, tsr.data(), tsr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));

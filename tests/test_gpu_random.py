@@ -96,3 +96,47 @@ def test_sync_table_receivers_random(case, dsss, lead, cfo_hz, fading, n_fo, see
             assert relerr(blk.est_data_freq_d, o.est_data_freq_d) < 2e-5
         if ro.any():
             assert relerr(rb, ro) < 2e-5
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(rows=st.integers(1, 24), n_sym_tx=st.integers(0, 20), lead=st.integers(0, 130), cut=st.integers(0, 90), calls=st.integers(1, 3),
+       sigma=st.sampled_from([0.0, 0.01, 0.1]), seed=st.integers(0, 2 ** 31 - 1), pat=st.sampled_from([(1, 3), (1, 1), (2, 2)]))
+def test_stream_block_differential_fuzz(rows, n_sym_tx, lead, cut, calls, sigma, seed, pat):
+    """utsa_ofdm.SynchAndChanEst.work vs the fp64 oracle on buffers of arbitrary length (empty, shorter than a symbol, ragged tails),
+    row counts that do or do not match the reference's reshape, several [S, D] patterns and call sequences: either both raise the
+    same exception type (IndexError / ValueError, like NumPy does in the reference) or state and outputs agree."""
+    import utsa_ofdm
+    N, cp, Kd = 64, 16, 60
+    S, D = pat
+    rng = np.random.default_rng(seed)
+    n_data = sum(1 for s in range(n_sym_tx) if s % (S + D) >= S)
+    bits = rng.integers(0, 2, max(n_data, 1) * Kd * 2)
+    tx = orc.tx_modulate(bits, N, cp, N - 2, Kd, n_sym_tx, synch_dat=(S, D), zc_segments=True) if n_sym_tx else np.zeros(0, complex)
+    body = np.concatenate([np.zeros(lead), tx, np.zeros(30)])
+    body = body[:max(0, len(body) - cut)]
+    iq = (body + sigma * (rng.standard_normal(len(body)) + 1j * rng.standard_normal(len(body)))).astype(np.complex64)
+    o = orc.RxOracle(rows, N, cp, N - 2, [S, D], Kd, 100, 0.7, force_fp64=True)
+    blk = utsa_ofdm.SynchAndChanEst(rows, N, cp, N - 2, [S, D], Kd, 100, 0.7, "/tmp/ofdm_fz_", "c", 0, 0, "Fading")
+    for _ in range(calls):
+        ro, rb = np.zeros(len(iq), np.complex64), np.zeros(len(iq), np.complex64)
+        eo = eb = None
+        try:
+            o.work(iq, ro)
+        except (IndexError, ValueError) as e:
+            eo = type(e)
+        try:
+            blk.work([iq], [rb])
+        except (IndexError, ValueError) as e:
+            eb = type(e)
+        m = np.max(np.abs(o.del_mat)) if getattr(o, "del_mat", None) is not None and np.size(o.del_mat) else 0.0
+        if abs(m - 0.7 * o.MM) < 2e-3 * o.MM:
+            return                                          # detection decided within fp32 rounding of the gate
+        assert eo == eb, (eo, eb)
+        assert np.array_equal(np.asarray(blk.time_synch_ref)[0:2], np.asarray(o.time_synch_ref)[0:2])
+        assert blk.count == o.count and blk.corr_obs == o.corr_obs
+        if np.isfinite(o.est_data_freq).all() and np.abs(o.est_chan_freq_P[0][o.bins_used_P]).min() > 1e-2:
+            assert relerr(blk.est_data_freq, o.est_data_freq) < 2e-5
+            if eo is None:
+                assert relerr(rb, ro) < 2e-5 or not ro.any()
+        if eo is not None:
+            return
