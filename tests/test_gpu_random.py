@@ -201,3 +201,56 @@ def test_tracker_block_differential_fuzz(n_sym, lead, cut, tail, fading, sigma, 
             _same_rows(rb[None, :60], ro[None, :60])
         if eo is not None:
             return
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(logn=st.integers(6, 9), S=st.integers(1, 3), D=st.integers(1, 3), kd_frac=st.floats(0.2, 0.95), rows=st.integers(2, 30),
+       n_pat=st.integers(0, 6), lead=st.integers(0, 90), cut=st.integers(0, 70), snr=st.sampled_from([50.0, 1e3, 1e8]),
+       fading=st.booleans(), calls=st.integers(1, 3), seed=st.integers(0, 2 ** 31 - 1))
+def test_table_mode_differential_fuzz(logn, S, D, kd_frac, rows, n_pat, lead, cut, snr, fading, calls, seed):
+    """RXOFDM.synch_and_chan_est(table_mode=True) (== the legacy OFDMReceiver.SynchAndChanEst) with arbitrary constructor arguments
+    vs the oracle: sync table, estimates, one data symbol per sync, output rows; same exception type when the reference raises
+    (101st sync, reshape / output size)."""
+    import RXOFDM
+    N = 1 << logn
+    cp = N // 4
+    Ks = N - 2
+    Kd = max(4, int((N - 2) * kd_frac) // 2 * 2)
+    rng = np.random.default_rng(seed)
+    n_sym = n_pat * (S + D)
+    n_data = n_pat * D
+    bits = rng.integers(0, 2, max(n_data, 1) * Kd * 2)
+    tx = (orc.tx_modulate(bits, N, cp, Ks, Kd, n_sym, synch_dat=(S, D), zc_root=37, zc_segments=True, zc_parity_of_bins=True)
+          if n_sym else np.zeros(0, complex))
+    if fading and n_sym:
+        tx = orc.channel_apply(tx, orc.REF_TAPS, N)[:len(tx) + 8]
+    body = np.concatenate([np.zeros(lead), tx, np.zeros(2 * cp)])
+    iq = body[:max(0, len(body) - cut)].astype(np.complex64)
+    o = orc.FoOracle.from_params(rows, N, cp, Ks, (S, D), Kd, snr, force_fp64=True)
+    blk = RXOFDM.synch_and_chan_est(rows, N, cp, Ks, [S, D], Kd, snr, "/tmp/ofdm_tf_", "c", 0, 0, table_mode=True)
+    n_out = max(len(iq), (rows // (S + D)) * Kd)
+    for _ in range(calls):
+        ro, rb = np.zeros(n_out, np.complex64), np.zeros(n_out, np.complex64)
+        eo = eb = None
+        try:
+            o.work(iq, ro)
+        except (IndexError, ValueError) as e:
+            eo = type(e)
+        try:
+            blk.work([iq], [rb])
+        except (IndexError, ValueError) as e:
+            eb = type(e)
+        t = o.time_synch_ref
+        n_sync = int(np.count_nonzero(t[:, 2]))
+        if np.any(np.abs(t[:n_sync, 2] - 0.4 * o.MM) < 2.0):
+            return
+        assert eo == eb, (eo, eb)
+        assert np.array_equal(blk.time_synch_ref[:, 0:2], t[:, 0:2])
+        if n_sync and np.abs(o.est_chan_freq_P[:n_sync][:, o.bins_used_P]).min() < 0.03:
+            return
+        _same_rows(blk.est_chan_freq_P, o.est_chan_freq_P)
+        _same_rows(blk.est_data_freq, o.est_data_freq)
+        if eo is None and np.isfinite(ro).all():
+            assert relerr(rb, ro) < 2e-5 or not ro.any()
+        if eo is not None:
+            return
