@@ -105,16 +105,6 @@ def cpu_baseline(cfg, iq_host):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-class _Shift:
-    """rehearsal helper: presents a host copy of rows [f0,f1) under the indices of the full tensor"""
-
-    def __init__(self, t, f0):
-        self.t, self.f0 = t, f0
-
-    def __getitem__(self, sl):
-        return self.t[sl.start - self.f0:sl.stop - self.f0]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,46 +166,22 @@ def main():
     nds = rxe.data_symbols_per_frame(fl)
     bytes_per_frame_bits = nds * Kd * bps // 8
     d_eq = None if args.no_eq else torch.empty((n_frames, nds, Kd, 2), dtype=torch.float32, device="cuda")
-    # N>1: two generations of bit / receive buffers.  Step i's all-gather then runs under step i+1's demod; the launch stream
-    # waits for a gather only when the buffers it read and wrote are about to be reused, two steps later.
-    GEN = 2 if world > 1 else 1
-    bits_gen = [torch.empty((n_frames, bytes_per_frame_bits), dtype=torch.uint8, device="cuda") for _ in range(GEN)]
-    d_bits = bits_gen[0]
-    gathered = None
     stream = torch.cuda.current_stream().cuda_stream
-
     bounds = od.sub_batches(n_frames, args.chunks if world > 1 else 1)
     n_chunks = len(bounds)
-    gathered_gen = None
-    if world > 1:
-        gathered_gen = [od.alloc_gather_buffers(torch, world, bounds, bytes_per_frame_bits, "cpu" if rehearsal else "cuda")
-                        for _ in range(GEN)]
-    pending = [[None] * n_chunks for _ in range(GEN)]
+    # N>1: two generations of bit / receive buffers (ofdm_mi355x.dist.GatherPipeline): step i's all-gather runs under step i+1's
+    # demod; the launch stream waits for a gather only when the buffers it read and wrote are about to be reused.
+    pipe = od.GatherPipeline(dist, torch, world, bounds, n_frames, bytes_per_frame_bits, "cuda",
+                             recv_device="cpu" if rehearsal else "cuda", host_staging=rehearsal)
     k_sync, k_demod = [], []
-    it = [0]
+
+    def produce(bits, f0, f1):
+        rxe.demod_frames(d_rx[f0:f1], f1 - f0, fl, fl, None if d_eq is None else d_eq[f0:f1], bits[f0:f1], om.BITS_PACKED, None, stream)
 
     def step():
-        g = it[0] % GEN
-        bits = bits_gen[g]
-        for ci, (f0, f1) in enumerate(bounds):
-            nf = f1 - f0
-            if pending[g][ci] is not None:
-                pending[g][ci].wait()         # stream-ordered: the gather that read bits[f0:f1] two steps ago
-                pending[g][ci] = None
-            rxe.demod_frames(d_rx[f0:f1], nf, fl, fl, None if d_eq is None else d_eq[f0:f1], bits[f0:f1],
-                             om.BITS_PACKED, None, stream)
-            if world > 1:
-                # equal counts per rank; rank r's frames [f0,f1) land at gathered[r, f0:f1]
-                src = _Shift(bits[f0:f1].cpu(), f0) if rehearsal else bits
-                pending[g][ci] = od.all_gather_bits(dist, gathered_gen[g][ci], src, f0, f1, async_op=True)
-        it[0] += 1
+        pipe.step(produce)
 
-    def drain():
-        for g in range(GEN):
-            for ci in range(n_chunks):
-                if pending[g][ci] is not None:
-                    pending[g][ci].wait()
-                    pending[g][ci] = None
+    drain = pipe.drain
 
     for _ in range(args.warmup):
         step()
@@ -248,9 +214,7 @@ def main():
 
     # ---- correctness spot check of what was timed (rank 0): bit errors of frame 0 vs the transmitted bits
     ber = None
-    d_bits = bits_gen[(it[0] - 1) % GEN]     # what the last step produced
-    if world > 1:
-        gathered = gathered_gen[(it[0] - 1) % GEN]
+    d_bits, gathered = pipe.last()            # what the last step produced
     if rank == 0:
         rxb = d_bits[0].cpu().numpy()
         txb = tx_bits[0].cpu().numpy()

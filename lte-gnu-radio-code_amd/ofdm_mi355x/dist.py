@@ -37,3 +37,50 @@ def all_gather_bits(dist, recv, local_bits, f0: int, f1: int, async_op: bool = T
 def reassemble(torch, recv_list, world: int):
     """[world, n_frames, row_bytes] copy of the whole bit-stream from the per-sub-batch receive buffers."""
     return torch.cat([r.view(world, r.shape[0] // world, r.shape[1]) for r in recv_list], dim=1)
+
+
+class GatherPipeline:
+    """Step loop of the N > 1 path: per sub-batch `produce` (the demod launch) followed by an asynchronous all-gather of the
+    rows it wrote, with `generations` sets of bit / receive buffers.  A buffer set is reused every `generations` steps and the
+    launch stream waits for the gather that last used it only then, so the gathers of step i run under the demod of step i+1:
+    the loop is bound by max(demod, fabric), not by their sum.  `drain()` completes everything outstanding.
+
+    With world == 1 nothing is gathered (one generation, `produce` only).  `host_staging` gathers host copies of the rows
+    (gloo rehearsal of the control flow on a box with fewer GPUs than ranks)."""
+
+    def __init__(self, dist, torch, world, bounds, n_rows, row_bytes, device, recv_device=None, generations=2, host_staging=False):
+        self.dist, self.torch, self.world, self.bounds = dist, torch, world, list(bounds)
+        self.gen = generations if world > 1 else 1
+        self.host_staging = host_staging
+        self.bits = [torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=device) for _ in range(self.gen)]
+        self.recv = None
+        if world > 1:
+            self.recv = [alloc_gather_buffers(torch, world, self.bounds, row_bytes, recv_device or device) for _ in range(self.gen)]
+        self.pending = [[None] * len(self.bounds) for _ in range(self.gen)]
+        self.steps = 0
+
+    def step(self, produce):
+        """produce(bits, f0, f1): fill rows [f0, f1) of `bits` (asynchronously on the current stream)."""
+        g = self.steps % self.gen
+        bits = self.bits[g]
+        for ci, (f0, f1) in enumerate(self.bounds):
+            if self.pending[g][ci] is not None:
+                self.pending[g][ci].wait()          # stream-ordered: the gather that read bits[f0:f1] `generations` steps ago
+                self.pending[g][ci] = None
+            produce(bits, f0, f1)
+            if self.world > 1:
+                src = bits[f0:f1].cpu() if self.host_staging else bits[f0:f1].contiguous()
+                self.pending[g][ci] = self.dist.all_gather_into_tensor(self.recv[g][ci], src, async_op=True)
+        self.steps += 1
+
+    def drain(self):
+        for row in self.pending:
+            for ci, w in enumerate(row):
+                if w is not None:
+                    w.wait()
+                    row[ci] = None
+
+    def last(self):
+        """(bits, receive buffers) of the most recent step."""
+        g = (self.steps - 1) % self.gen
+        return self.bits[g], (self.recv[g] if self.recv is not None else None)

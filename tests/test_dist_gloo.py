@@ -82,3 +82,70 @@ def test_shard_helpers():
         od.shard_frames(10, 4, 0)
     assert od.sub_batches(10, 4) == [(0, 2), (2, 5), (5, 7), (7, 10)]
     assert od.sub_batches(2, 4) == [(0, 1), (1, 2)]
+
+
+def _pipeline_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "lte-gnu-radio-code_amd")]
+    from ofdm_mi355x import dist as od
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_rows, row_bytes, steps = 11, 96, 5
+    bounds = od.sub_batches(n_rows, 4)
+    pipe = od.GatherPipeline(dist, torch, world, bounds, n_rows, row_bytes, "cpu")
+    history = []
+
+    def make(step):
+        def produce(bits, f0, f1):
+            # the "demod" of this rank: a pattern that depends on (rank, step, row, byte)
+            r = torch.arange(f0, f1).view(-1, 1)
+            c = torch.arange(row_bytes).view(1, -1)
+            bits[f0:f1] = ((rank * 131 + step * 17 + r * 7 + c) % 251).to(torch.uint8)
+        return produce
+
+    for s in range(steps):
+        pipe.step(make(s))
+    pipe.drain()
+    bits, recv = pipe.last()
+    full = od.reassemble(torch, recv, world)
+    q.put((rank, full.numpy().copy(), bits.numpy().copy(), pipe.steps, pipe.gen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_pipeline_two_generations():
+    """The step loop bench.py runs at N > 1 (GatherPipeline: per sub-batch produce + async all-gather, two buffer generations,
+    deferred waits, drain) with 2 gloo ranks on CPU: after 5 steps every rank holds both ranks' rows of the LAST step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_rows, row_bytes, last = 11, 96, 4
+    r = np.arange(n_rows).reshape(-1, 1)
+    c = np.arange(row_bytes).reshape(1, -1)
+    expect = np.stack([((rk * 131 + last * 17 + r * 7 + c) % 251).astype(np.uint8) for rk in range(world)])
+    for rank, full, bits, steps, gen in res:
+        assert steps == 5 and gen == 2
+        assert np.array_equal(full, expect)
+        assert np.array_equal(bits, expect[rank])
+
+
+def test_gather_pipeline_single_rank_is_a_plain_loop():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "lte-gnu-radio-code_amd")]
+    from ofdm_mi355x import dist as od
+    pipe = od.GatherPipeline(None, torch, 1, od.sub_batches(6, 1), 6, 8, "cpu")
+    calls = []
+    pipe.step(lambda bits, f0, f1: calls.append((f0, f1)))
+    pipe.drain()
+    assert calls == [(0, 6)] and pipe.gen == 1 and pipe.last()[1] is None
