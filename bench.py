@@ -105,6 +105,37 @@ def cpu_baseline(cfg, iq_host):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def _power_sample(torch, step, seconds=3.0):
+    """[median package power W, median shader clock MHz] from rocm-smi while `step` runs back to back for `seconds` (untimed)."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        time.sleep(1.0)
+        while not stop[0]:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+            pw = re.search(r"Package Power \(W\): ([0-9.]+)", out)
+            ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            if pw and ck:
+                samples.append((float(pw.group(1)), int(ck.group(1))))
+            time.sleep(0.2)
+
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    if not samples:
+        return None
+    return [float(np.median([a for a, _ in samples])), float(np.median([b for _, b in samples]))]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,13 +292,23 @@ def main():
                 if d_eq is not None:
                     pms, _ = _probe(1)
                     pat_gbs = dsym * (L * 8 + Kd * 8) / pms / 1e6
+            # same-run context: package power and shader clock while the step runs back to back (untimed extra loop; rocm-smi).
+            # On the pool's chips this kernel sits at the ~1.3 kW package limit with the shader clock throttled below the
+            # 2.4 GHz the memory-only probes run at.
+            power = None
+            if world == 1:
+                try:
+                    power = _power_sample(torch, step)
+                except Exception:
+                    power = None
             roof = dict(bound="hbm", kernel="rx_demod_kernel<%d>" % N, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                         algorithmic_bytes_per_launch=int(alg), kernel_ms=round(dm, 4),
                         sync_kernel_ms=round(float(np.mean(k_sync)), 4),
                         read_only_frac=round(dsym * L * 8 / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         measured_copy_GBs=None if copy_gbs is None else round(copy_gbs, 1),
-                        access_pattern_no_math_GBs=None if pat_gbs is None else round(pat_gbs, 1))
+                        access_pattern_no_math_GBs=None if pat_gbs is None else round(pat_gbs, 1),
+                        package_power_w_and_sclk_mhz_under_load=power)
         cpu = None
         if world == 1 and not args.no_cpu:
             iq_host = d_rx[:16].cpu().numpy().view(np.complex64).reshape(16, fl)

@@ -25,7 +25,7 @@ d_bits = torch.empty((n_frames, nds * Kd * bps // 8), dtype=torch.uint8, device=
 st = torch.cuda.current_stream().cuda_stream
 res = {v: [] for v in variants}
 ref = None
-for rnd in range(10):
+for rnd in range(int(os.environ.get("KB_ROUNDS", "10"))):
     for v in variants:
         rxe.set_variant(v)
         rxe.demod_frames(d_rx, n_frames, fl, fl, None if os.environ.get('KB_NOEQ') == '1' else d_eq, d_bits, om.BITS_PACKED, None, st)
