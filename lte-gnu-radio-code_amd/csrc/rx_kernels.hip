@@ -18,9 +18,9 @@ namespace ofdm {
 // One sync trial P of one frame (SynchAndChanEst.py:145-164).  On return: Z (per-lane bins, register
 // slot order) = sum over the S sync symbols of Y[k]*conj(zc), zdup = negative-half part of a bin that
 // is listed twice (K == N only), p_est, m = max|del_mat|, dhat = argmax lag.
-template <int N>
+template <int N, class TW>
 __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, int64_t frame_len, bool active,
-                                           int Ptrial, cf* lds, float* red, const LaneTwiddles<N>& tw, const cf* w1tab, int t,
+                                           int Ptrial, cf* lds, float* red, const TW& tw, const cf* w1tab, int t,
                                            cf (&Z)[Plan<N>::P], cf& zdup, float& p_est, float& m, int& dhat,
                                            cf* yscratch, const cf* rot = nullptr, int off = 0) {
     using PL = Plan<N>;
@@ -118,8 +118,9 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, Sy
     float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
     const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
 
-    LaneTwiddles<N> tw;
-    load_twiddles<N>(tw, rx.tw, t);
+    // radix-16 first pass: 4 base twiddles + products on the fly (8 VGPRs instead of 30) keep the 168-register build off scratch
+    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, rx.tw, t);
 
     const int64_t unit = int64_t(blockIdx.x) * PL::SLOTS + slot;
     const int Ks = rx.Ks, Kd = rx.Kd;
