@@ -296,7 +296,8 @@ def main():
             # On the pool's chips this kernel sits at the ~1.3 kW package limit with the shader clock throttled below the
             # 2.4 GHz the memory-only probes run at.
             power = None
-            if world == 1:
+            profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+            if world == 1 and not profiled:     # no child processes under a profiler's preload
                 try:
                     power = _power_sample(torch, step)
                 except Exception:
