@@ -68,3 +68,29 @@ def test_safe_pickle_rejects_code_execution(tmp_path):
         assert np.array_equal(load_ndarray(str(p)), a)
     f = np.asfortranarray(np.arange(6, dtype=np.int32).reshape(2, 3))
     assert np.array_equal(loads_ndarray(pickle.dumps(f, protocol=2)), f)
+
+
+def test_product_tree_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under the package directory may import it, and nothing shipped (package,
+    bench.py, __graft_entry__.py) may read /root/reference at run time."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "lte-gnu-radio-code_amd")
+    offenders = []
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".c")):
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or re.search(r"#\s*include[^\n]*oracle", text):
+                    offenders.append(os.path.join(dp, f))
+                if re.search(r"open\([^)]*/root/reference|load[^(]*\([^)]*/root/reference", text):
+                    offenders.append(os.path.join(dp, f) + " (reads the reference)")
+    for f in ("bench.py", "__graft_entry__.py"):
+        text = open(os.path.join(root, f)).read()
+        for m in re.finditer(r"/root/reference[^\s\"')]*", text):
+            line = text[:m.start()].count("\n") + 1
+            src = text.splitlines()[line - 1]
+            if not src.lstrip().startswith("#") and "os.path.isdir" not in src and "exists" not in src:
+                offenders.append("%s:%d %s" % (f, line, src.strip()))
+    assert not offenders, offenders
