@@ -120,14 +120,6 @@ int ofdm_rx_get_frame_state(ofdm_rx* h, int64_t frame, float* h_chan_freq, float
 int ofdm_rx_set_profiling(ofdm_rx* h, int32_t enable);
 int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms);
 
-/* Kernel tuning variant of the demod kernel (0 = shipped default; other values select alternative
- * register/LDS/prefetch trade-offs compiled into the library).  Results are identical. */
-int ofdm_rx_set_variant(ofdm_rx* h, int32_t variant);
-
-/* Diagnostic only (variant 9, N = 2048): device buffer of 8 uint32 per wave receiving per-phase cycle sums
- * (s_memtime stamps).  The stamped build is never the one that is timed. */
-int ofdm_rx_set_stamp_buffer(ofdm_rx* h, void* d_stamps);
-
 /* Upper bound on sync trials per frame in the batch path (0 = none: scan the whole frame like the
  * reference, :143).  A frame with no sync costs one FFT pair per sample, so hosts may cap it. */
 int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials);

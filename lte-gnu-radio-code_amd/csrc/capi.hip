@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "../../include/ofdm_mi355x.h"
+#ifdef OFDM_EXPERIMENTS
+#include "../../tools/experiments/ofdm_experiments.h"
+#endif
 #include "ofdm_launch.hpp"
 
 using namespace ofdm;
@@ -283,17 +286,21 @@ int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms) {
     return OFDM_OK;
 }
 
-int ofdm_rx_set_variant(ofdm_rx* h, int32_t variant) {
+#ifdef OFDM_EXPERIMENTS
+// Bench-only build (tools/experiments/ofdm_experiments.h): kernel tuning variants and the s_memtime-stamped diagnostic.
+// Not part of the product ABI and not compiled into libofdm_mi355x.so.
+int ofdm_exp_set_variant(ofdm_rx* h, int32_t variant) {
     if (!h || variant < 0) return fail(OFDM_ERR_INVALID, "bad argument");
     h->variant = variant;
     return OFDM_OK;
 }
 
-int ofdm_rx_set_stamp_buffer(ofdm_rx* h, void* d_stamps) {
+int ofdm_exp_set_stamp_buffer(ofdm_rx* h, void* d_stamps) {
     if (!h) return fail(OFDM_ERR_INVALID, "null handle");
     h->d_stamps = static_cast<unsigned*>(d_stamps);
     return OFDM_OK;
 }
+#endif
 
 int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials) {
     if (!h || max_trials < 0) return fail(OFDM_ERR_INVALID, "bad argument");
@@ -1198,7 +1205,11 @@ int ofdm_trk_demod(ofdm_trk* h, int32_t n_sync, const int64_t* h_ptr, const uint
     std::vector<int> tsr(size_t(n_sync) * 4, 0);
     int last = -1;
     for (int p = 0; p < n_sync; ++p) {
-        tsr[size_t(p) * 4 + 0] = int(h_ptr[p]);
+        if (h_guard[p] && (h_ptr[p] < 0 || h_ptr[p] > INT32_MAX - int64_t(d.S + D) * d.L))
+            // a guarded window that starts before the buffer: the reference's slice would wrap / be empty and the block
+            // mirror raises IndexError for it; never hand a negative start to the kernel
+            return fail(OFDM_ERR_INDEX, "sync %d: window pointer %lld outside the buffer", p, (long long)h_ptr[p]);
+        tsr[size_t(p) * 4 + 0] = h_guard[p] ? int(h_ptr[p]) : 0;
         tsr[size_t(p) * 4 + 3] = h_guard[p] ? 1 : 0;
         if (!h_guard[p]) continue;
         if (p * D + D - 1 >= h->cfg.rows_data)

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     };
     cf v[P];
     auto load_sym = [&](const Sym& sy) {
-        if (sy.compute && sy.start + N <= a.frame_len) {
+        if (sy.compute && sy.start >= 0 && sy.start + N <= a.frame_len) {
             const cf* src = frame_iq + sy.start + t;
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) v[n0] = NT ? __builtin_nontemporal_load(src + T * n0) : src[T * n0];
@@ -271,8 +271,8 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) {
                 const int64_t idx = sy.start + t + T * n0;
-                const cf x = any ? frame_iq[idx < last ? idx : last] : cf{0.f, 0.f};
-                v[n0] = (any && idx < a.frame_len) ? x : cf{0.f, 0.f};
+                const cf x = any ? frame_iq[idx < 0 ? 0 : (idx < last ? idx : last)] : cf{0.f, 0.f};
+                v[n0] = (any && idx >= 0 && idx < a.frame_len) ? x : cf{0.f, 0.f};
                 if constexpr (ROT) v[n0] = cmul(v[n0], a.rot[t + T * n0]);
             }
         }
@@ -447,7 +447,9 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     }
     const unsigned grid = unsigned(int64_t(a.n_frames) * a.chunks_per_frame);
     size_t lds = DG::lds_bytes(rx.Kd, true);
+#ifdef OFDM_EXPERIMENTS
     if (a.variant >= 100) lds += size_t(a.variant - 100) * 1024;   // occupancy experiment: pad the LDS request by (variant-100) KiB
+#endif
     const int bmode = a.bits ? a.bits_mode : 0;
     if (a.host_guard) {             // tracker receiver: equalised symbols only, frames enabled by the host
         if (bmode != 0 || a.rot) return hipErrorInvalidValue;
@@ -459,7 +461,10 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, true, false, true, false, true, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
         return hipGetLastError();
     }
-    if constexpr (N == 2048) {      // tuning variants (ofdm_rx_set_variant): 16-QAM packed only
+#ifdef OFDM_EXPERIMENTS
+    // Tuning / diagnostic builds (tools/experiments: libofdm_mi355x_exp.so, ofdm_exp_set_variant): 16-QAM packed only.
+    // None of them is compiled into the product library; an unknown variant falls through to the shipped kernel.
+    if constexpr (N == 2048) {
         if (a.variant != 0 && a.variant < 100 && bmode == 1 && a.mod == 4) {
             if (a.variant == 1) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 2) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, true>), dim3(grid), dim3(DG::WG), DG::lds_bytes(rx.Kd, false), s, rx, a);
@@ -469,9 +474,10 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             if (a.variant == 7) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 8) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 4, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            return hipGetLastError();
+            if (a.variant >= 1 && a.variant <= 9 && a.variant != 4) return hipGetLastError();
         }
     }
+#endif
 #define OFDM_LD(M, B) \
     hipLaunchKernelGGL((rx_demod_kernel<N, M, B, 3>), dim3(grid), dim3(DG::WG), lds, s, rx, a)
 #define OFDM_LD_MOD(B)                  \

@@ -93,8 +93,6 @@ PROTOTYPES = {
     "ofdm_rx_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "ofdm_rx_get_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ofdm_rx_set_max_trials": (C.c_int, [C.c_void_p, C.c_int32]),
-    "ofdm_rx_set_variant": (C.c_int, [C.c_void_p, C.c_int32]),
-    "ofdm_rx_set_stamp_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ofdm_demap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofdm_fo_create": (C.c_int, [C.POINTER(FoCfg), C.POINTER(C.c_void_p)]),
     "ofdm_fo_destroy": (C.c_int, [C.c_void_p]),
@@ -117,17 +115,66 @@ PROTOTYPES = {
 }
 
 _lib = None
+hip_runtime_path = None     # the libamdhip64 this process ended up with (diagnostic)
+
+
+def _mapped_hip_runtimes():
+    """Paths of every libamdhip64 mapped into this process (Linux)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64" in path and path not in found:
+                    found.append(path)
+    except OSError:
+        pass
+    return found
+
+
+def _pin_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    libofdm_mi355x.so needs `libamdhip64.so.7`; the PyTorch-ROCm wheel ships its own library under the SAME soname.  The
+    dynamic linker keeps whichever was mapped first for both users.  The system runtime first and torch second leaves torch
+    on a runtime it was not built for (`RuntimeError: No HIP GPUs are available` on the first torch.cuda call); torch's
+    runtime first works for both.  So: when torch is installed (found WITHOUT importing it) and no HIP runtime is mapped yet,
+    map torch's bundled runtime first.  Hosts without torch (GNU Radio, the C example) get the system runtime.
+    OFDM_MI355X_SYSTEM_HIP=1 opts out."""
+    global hip_runtime_path
+    mapped = _mapped_hip_runtimes()
+    if mapped:
+        hip_runtime_path = mapped[0]
+        return
+    if os.environ.get("OFDM_MI355X_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+    import sys
+    try:
+        spec = sys.modules["torch"].__spec__ if "torch" in sys.modules else importlib.util.find_spec("torch")
+    except (ImportError, ValueError, AttributeError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            hip_runtime_path = cand
+        except OSError:
+            pass
 
 
 def load():
     """Load the shared library (once).  Raises OfdmLibraryError when it is absent: there is no fallback."""
-    global _lib
+    global _lib, hip_runtime_path
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise OfdmLibraryError(
             "HIP library %s not found: build it with `make -C lte-gnu-radio-code_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    _pin_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)          # CDLL calls release the GIL (GNU Radio: one thread per block)
     except OSError as e:
@@ -141,6 +188,12 @@ def load():
         fn.argtypes = args
     if lib.ofdm_abi_version() != 1:
         raise OfdmLibraryError("ABI version mismatch")
+    mapped = _mapped_hip_runtimes()
+    if len(mapped) > 1:
+        raise OfdmLibraryError("two HIP runtimes are mapped into this process (%s): import ofdm_mi355x before anything else "
+                               "that loads libamdhip64, or import torch first" % ", ".join(mapped))
+    if mapped:
+        hip_runtime_path = mapped[0]
     _lib = lib
     return lib
 

@@ -19,6 +19,7 @@ from . import _lib
 from .engine import DeviceBuffer, FoEngine, RxEngine, TrkEngine, bins_p, zadoff_chu
 from .gr_compat import sync_block
 from .safe_pickle import load_ndarray
+from .tracker import SyncPointerTracker
 
 
 def _device() -> int:
@@ -340,10 +341,9 @@ class SynchronizeAndEstimate(sync_block):
     one sync symbol per [1,3] pattern (fixed advance for the first five, a least-squares line through the last five
     (position + lag) observations afterwards), LS channel estimate per sync and three equalised data symbols per sync.
 
-    The pointer logic below is the reference's scalar control flow, statement for statement (:209-350); every array
-    computation -- windows, FFTs, lag correlation, channel estimate, equaliser, renormalisation -- runs on the GPU through
-    `TrkEngine`.  The regression uses `np.linalg.lstsq` exactly as the reference does (:341): the predicted pointer goes
-    through `ceil`, so the host keeps the same LAPACK routine rather than a closed form that could differ in the last bit.
+    The scalar pointer logic lives in `tracker.SyncPointerTracker` (an acquire / coast / predict state machine pinned to the
+    recorded reference runs); every array computation -- windows, FFTs, lag correlation, channel estimate, equaliser,
+    renormalisation -- runs on the GPU through `TrkEngine`.
     """
 
     def __init__(self, case):
@@ -412,84 +412,36 @@ class SynchronizeAndEstimate(sync_block):
         out = output_items[0]
         eng = self._engine
         n_in = in0.shape[0]
-        N, cp, L, m = self.NFFT, self.len_CP, self.rx_buff_len, 0
+        N = self.NFFT
         eng.load(in0)
-        self.stride_val = np.ceil(cp / 2)                                         # :209
-        ptr_frame, b, xp = 0, 0, []
-        self.corr_obs = -1                                                        # :216
-        self.start_samp = (cp - 4) - 1                                            # :219
-        total_loops = int(np.ceil(n_in / self.stride_val))
-        ptr_adj, loop_count, sym_count = 0, 0, 0
-        tap_delay = 5
-        x = np.zeros(tap_delay)
-        ptr_synch0 = np.zeros(1000)
-        sd = int(sum(self.synch_data))
-        # acquisition windows (corr_obs == -1: ptr_adj is still 0) are independent: one batched launch
-        step, first = int(self.stride_val), int(self.start_samp)
-        n_acq = 0
-        while n_acq <= total_loops and N + (n_acq * step + first) < n_in:         # :240
-            n_acq += 1
-        acq_peak, acq_lag = eng.trials(first, step, n_acq)
-        memo = {}
+        trk = SyncPointerTracker(N, self.len_CP, int(sum(self.synch_data)), 0.5 * self.MM, self.time_synch_ref[0])
+        self.stride_val, self.start_samp = trk.scan_step, trk.scan_origin           # :209,219
+        # the acquisition windows are independent of each other: one batched launch for the whole scan
+        scan_peak, scan_lag = eng.trials(int(trk.scan_origin), int(trk.scan_step), trk.scan_length(n_in))
+        seen = {}
 
-        def trial(ptr):
-            key = int(ptr)
-            if key not in memo:
-                pk, lg = eng.trials(key, 1, 1)
-                memo[key] = (float(pk[0]), int(lg[0]))
-            return memo[key]
+        def probe(window):
+            if window not in seen:                       # the late-lag branch can ask for the same window twice
+                pk, lg = eng.trials(window, 1, 1)
+                seen[window] = (float(pk[0]), int(lg[0]))
+            return seen[window]
 
-        while loop_count <= total_loops:                                          # :230
-            if self.corr_obs == -1:
-                ptr_frame = loop_count * self.stride_val + self.start_samp + ptr_adj
-            elif self.corr_obs < 5:
-                ptr_frame += sd * (N + cp)
-            else:
-                ptr_frame = (np.ceil(np.dot(xp[-1:], b) - cp / 4))[0]            # :237
-            if N + ptr_frame < n_in:                                              # :240
-                window_ptr = int(ptr_frame)
-                if self.corr_obs == -1:
-                    dmax, dmax_ind0 = float(acq_peak[loop_count]), int(acq_lag[loop_count])
-                else:
-                    if window_ptr < 0:
-                        raise IndexError("window pointer %d before the buffer" % window_ptr)
-                    dmax, dmax_ind0 = trial(window_ptr)
-                dmax_ind = dmax_ind0 - 1                                          # :275
-                if dmax > 0.5 * self.MM or self.corr_obs > -1:                    # :279
-                    if dmax_ind > np.ceil(0.75 * cp):                             # :281 pointer moves, window does not
-                        if self.corr_obs == -1:
-                            ptr_adj += np.ceil(0.5 * cp)
-                            ptr_frame = loop_count * self.stride_val + self.start_samp + ptr_adj
-                        elif self.corr_obs < 5:
-                            ptr_frame += np.ceil(0.5 * cp)
-                    time_synch_ind = self.time_synch_ref[m, max(self.corr_obs, 1), 0]            # :311
-                    if ptr_frame - time_synch_ind > (2 * cp + N) or self.corr_obs == -1:         # :313
-                        self.corr_obs += 1
-                        self.time_synch_ref[m, self.corr_obs] = [ptr_frame, dmax_ind, dmax]      # :316-318
-                        ptr_synch0[sym_count % tap_delay] = sum(self.time_synch_ref[m, self.corr_obs, 0:2])
-                        x[sym_count % tap_delay] = sym_count * sd
-                        sym_count += 1
-                        x2 = x[0:min(self.corr_obs, tap_delay)]
-                        x_plus = np.concatenate((x2, np.atleast_1d(sym_count * sd)))
-                        xp = np.zeros((len(x_plus), 2))
-                        xp[:, 0] = 1
-                        xp[:, 1] = x_plus
-                        if self.corr_obs > 3:                                     # :333-341
-                            y = ptr_synch0[0:min(tap_delay, self.corr_obs)]
-                            X = np.zeros((len(x2), 2))
-                            X[:, 0] = 1
-                            X[:, 1] = x2
-                            b = np.linalg.lstsq(X, y, rcond=-1)[0]
-                        # LS estimate on the device (:344-378); a lag of -1 selects the LAST phase column there
-                        eng.accept(self.corr_obs, window_ptr, dmax_ind if dmax_ind >= 0 else cp, dmax_ind)
-            loop_count += 1
-        if self.num_ant_txrx == 1:                                                # :397
-            n_sync = self.corr_obs + 1
-            ptrs = [int(self.time_synch_ref[m, p, 0]) for p in range(n_sync)]
-            guards = [bool(sum(self.time_synch_ref[m, p, :]) + N < n_in) for p in range(n_sync)]  # :401
+        def accept(row, window, lag):
+            # LS estimate on the device (:344-378); a lag of -1 selects the LAST phase column there
+            eng.accept(row, window, lag if lag >= 0 else self.len_CP, lag)
+
+        self.corr_obs = -1                                                           # :216
+        try:
+            trk.run(n_in, lambda i: (float(scan_peak[i]), int(scan_lag[i])), probe, accept)
+        finally:
+            self.corr_obs = trk.n_found - 1          # also when the reference's IndexError ends the call early
+        if self.num_ant_txrx == 1:                                                   # :397
+            rows = self.time_synch_ref[0, :trk.n_found]
+            ptrs = [int(r[0]) for r in rows]
+            guards = [bool(sum(r) + N < n_in) for r in rows]                         # :401 (pointer + lag + PEAK)
             last_row, last = eng.demod(ptrs, guards)
             if last_row >= 0:
-                out[0:self.num_data_bins] = last                                  # :438-440
+                out[0:self.num_data_bins] = last                                     # :438-440
         return len(output_items[0])
 
 

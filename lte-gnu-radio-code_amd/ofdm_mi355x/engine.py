@@ -135,9 +135,6 @@ class RxEngine:
         check(self.lib.ofdm_rx_get_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
-    def set_variant(self, v: int):
-        check(self.lib.ofdm_rx_set_variant(self._h, int(v)))
-
     def set_max_trials(self, n: int):
         check(self.lib.ofdm_rx_set_max_trials(self._h, int(n)))
 

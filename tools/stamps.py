@@ -3,8 +3,9 @@
 mean cycles per phase per symbol (per wave).  Shares, not absolute times: the stamps serialise (cdna_hip_programming.md 7)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "lte-gnu-radio-code_amd")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools", "experiments")]
 import numpy as np, torch
+import explib                      # bench-only library (make -C lte-gnu-radio-code_amd/csrc exp)
 import ofdm_mi355x as om
 from ofdm_mi355x import _lib
 import bench
@@ -20,10 +21,10 @@ nds = rxe.data_symbols_per_frame(fl)
 d_eq = torch.empty((n_frames, nds, Kd, 2), dtype=torch.float32, device="cuda")
 d_bits = torch.empty((n_frames, nds * Kd * 4 // 8), dtype=torch.uint8, device="cuda")
 stamps = torch.zeros((65536 * 4, 8), dtype=torch.int32, device="cuda")
-_lib.check(rxe.lib.ofdm_rx_set_stamp_buffer(rxe._h, _lib.ptr(stamps)))
+explib.set_stamp_buffer(rxe, stamps)
 st = torch.cuda.current_stream().cuda_stream
 for v in (0, 9, 9):
-    rxe.set_variant(v)
+    explib.set_variant(rxe, v)
     rxe.demod_frames(d_rx, n_frames, fl, fl, d_eq, d_bits, om.BITS_PACKED, None, st)
     print("variant", v, "kernel ms", rxe.kernel_ms()[1])
 s = stamps.cpu().numpy().astype(np.int64)
