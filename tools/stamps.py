@@ -12,7 +12,7 @@ import bench
 
 cfg = dict(bench.CONFIGS["cfg2"]); n_frames = 2048
 torch.cuda.set_device(0)
-d_rx, _ = bench.build_inputs(torch, om, cfg, n_frames, 0, 1)
+d_rx, _, _ = bench.build_inputs(torch, om, cfg, n_frames, 0, 1)
 N, cp, Kd, n_sym = cfg["nfft"], cfg["cp"], cfg["Kd"], cfg["n_sym"]
 fl = n_sym * (N + cp)
 rxe = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 30, 0.7, modulation=cfg["mod"])
