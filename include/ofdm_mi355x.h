@@ -159,6 +159,36 @@ int ofdm_tx_destroy(ofdm_tx* h);
 int ofdm_tx_modulate_frames(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode, int64_t n_frames,
                             int32_t n_sym, float* d_iq, int64_t frame_stride, void* stream);
 
+/* ---- decomposed transmitter stages.  The reference names these blocks only in a flowgraph --
+ * txOFDM_random_bit_source -> txOFDM_ConstellationModulation(modulation) -> txOFDM_OFDM_Modulation(fft_size, pilot_locations)
+ * -> txOFDM_IFFT(fft_size) -> txOFDM_CyclicPrefix(fft_size, cp_size) -> txOFDM_SynchDataMux(fft_size, cp_size, prime_no,
+ * synch_every, synch_length)  (G/LEGACY/gr-ofdm-tx/grc/RXtransmit_6.grc:701-975, connections :1819-1854) -- and holds no
+ * code for them.  Each stage is the corresponding slice of MultiAntennaSystem.multi_ant_binary_map / multi_ant_symb_gen
+ * (:150-218) on device buffers; chained they equal ofdm_tx_modulate_frames bit for bit (the kernels share their device
+ * functions).  The handle's cfg supplies the numerology: modulation (map), nfft / num_data_bins (grid), cp_len (CP),
+ * num_synch_bins / zc_root / synch_S / synch_D (mux: S sync symbols before every D = synch_every data symbols). */
+/* random_bit_source: n_bits bits, one per byte, of a counter-based stream: bit k = bit (k%32) of word (k/32)%4 of
+ * Philox4x32-10(counter = k/128, key = seed); the window [offset, offset+n_bits) is produced (a stream block advances offset). */
+int ofdm_tx_random_bits(ofdm_tx* h, uint64_t seed, uint64_t offset, uint8_t* d_bits, int64_t n_bits, void* stream);
+/* ConstellationModulation: n_symbols * bps bits (MSB first per symbol; bits_mode as above) -> n_symbols complex64 (:150-178). */
+int ofdm_tx_map(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode, int64_t n_symbols, float* d_sym, void* stream);
+/* pilot_locations of OFDM_Modulation: signed bin offsets (e.g. -21,-7,7,21) inside the occupied span
+ * binsP(num_data_bins + n_pilots); those bins carry pilot_re + j pilot_im, the data symbols fill the other occupied bins in
+ * list order.  n_pilots = 0 (default) gives the reference grid (:182-183).  Host array, copied; synchronises the device. */
+int ofdm_tx_set_pilots(ofdm_tx* h, const int32_t* h_locations, int32_t n_pilots, float pilot_re, float pilot_im);
+/* OFDM_Modulation: d_sym [n_rows][num_data_bins] -> d_grid [n_rows][nfft] (unused bins and DC zero) (:135-183). */
+int ofdm_tx_grid(ofdm_tx* h, const float* d_sym, int64_t n_rows, float* d_grid, void* stream);
+/* IFFT (do_ifft=1, add_cp=0): [n_rows][nfft] grid rows -> [n_rows][nfft] time samples, numpy.fft.ifft scaling (:199).
+ * CyclicPrefix (0,1): [n_rows][nfft] time samples -> [n_rows][nfft+cp] CP-extended symbols, power-normalised as :200-218.
+ * (1,1): both in one launch. */
+int ofdm_tx_ifft_cp(ofdm_tx* h, const float* d_in, int64_t n_rows, int32_t do_ifft, int32_t add_cp, float* d_out, void* stream);
+/* SynchDataMux: d_data [n_data_sym][nfft+cp] -> d_out: synch_S Zadoff-Chu sync symbols in front of every synch_D data symbols
+ * (a trailing partial pattern keeps its sync symbols).  Returns the number of OUTPUT symbols
+ * (n/D*(S+D) + (n%D ? S + n%D : 0)) or a negative ofdm_status; d_out must hold that many symbols. */
+int64_t ofdm_tx_mux(ofdm_tx* h, const float* d_data, int64_t n_data_sym, float* d_out, void* stream);
+/* the sync symbol(s) the mux inserts: h_sync_time [synch_S][nfft+cp] complex64 */
+int ofdm_tx_get_sync_symbol(ofdm_tx* h, float* h_sync_time);
+
 /* Loop-back channel (MultiAntennaSystem.py:221-260): y = x (*) taps (taps used as given; the
  * reference normalises to unit norm first, :86) + complex AWGN of variance noise_var (Philox
  * counter-based, reproducible from `seed`).  Per frame: in_len input samples, out_len outputs

@@ -3,6 +3,7 @@
 // (SynchAndChanEst.work, gr-utsa_ofdm/python/SynchAndChanEst.py:135-262) and kernel launches.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -206,6 +207,11 @@ struct ofdm_tx {
     TxDev dev{};
     cf* d_tw = nullptr;
     cf* d_zc = nullptr;
+    // decomposed stages
+    cf* d_sync_time = nullptr;           // [S][L] the sync symbol(s) SynchDataMux inserts, synthesised once at creation
+    int* d_pilots = nullptr;             // ascending list indices into binsP(Kd + n_pilots)
+    int n_pilots = 0;
+    cf pilot_value = cf{1.f, 0.f};
 };
 
 extern "C" {
@@ -1262,8 +1268,11 @@ int ofdm_trk_get_state(ofdm_trk* h, float* h_chan_freq, float* h_chan_impulse, f
 int ofdm_tx_destroy(ofdm_tx* h) {
     if (!h) return OFDM_OK;
     (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->d_tw) (void)hipFree(h->d_tw);
     if (h->d_zc) (void)hipFree(h->d_zc);
+    if (h->d_sync_time) (void)hipFree(h->d_sync_time);
+    if (h->d_pilots) (void)hipFree(h->d_pilots);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return OFDM_OK;
@@ -1312,7 +1321,132 @@ int ofdm_tx_create(const ofdm_tx_cfg* c, ofdm_tx** out) {
     d.bps = c->modulation;
     d.tw = h->d_tw;
     d.zc = h->d_zc;
+    // the sync symbol(s) of SynchDataMux: ZC grid rows -> IFFT + CP + normalise, once (same kernels as the data symbols)
+    {
+        cf* d_grid = nullptr;
+        rc = dev_alloc(&d_grid, size_t(d.S) * N);
+        if (rc == OFDM_OK) rc = dev_alloc(&h->d_sync_time, size_t(d.S) * d.L);
+        if (rc == OFDM_OK) {
+            TimeArgs ta{};
+            ta.in = d_grid;
+            ta.n_rows = d.S;
+            ta.do_ifft = 1;
+            ta.do_cp = 1;
+            ta.out = h->d_sync_time;
+            if (launch_tx_sync_grid(d, d_grid, h->stream) != hipSuccess || launch_tx_time(d, ta, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess)
+                rc = fail(OFDM_ERR_HIP, "sync-symbol synthesis failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        if (d_grid) (void)hipFree(d_grid);
+        if (rc != OFDM_OK) {
+            std::string keep = g_last_error;
+            ofdm_tx_destroy(h);
+            g_last_error = keep;
+            return rc;
+        }
+    }
     *out = h;
+    return OFDM_OK;
+}
+
+// ---- decomposed stages
+int ofdm_tx_random_bits(ofdm_tx* h, uint64_t seed, uint64_t offset, uint8_t* d_bits, int64_t n_bits, void* stream) {
+    if (!h || (!d_bits && n_bits > 0) || n_bits < 0) return fail(OFDM_ERR_INVALID, "ofdm_tx_random_bits: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(launch_tx_random_bits(seed, offset, d_bits, n_bits, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+int ofdm_tx_map(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode, int64_t n_symbols, float* d_sym, void* stream) {
+    if (!h || n_symbols < 0 || (n_symbols > 0 && (!d_bits || !d_sym))) return fail(OFDM_ERR_INVALID, "ofdm_tx_map: bad argument");
+    if (bits_mode != OFDM_BITS_PACKED && bits_mode != OFDM_BITS_UNPACKED)
+        return fail(OFDM_ERR_INVALID, "bits_mode must be OFDM_BITS_PACKED or OFDM_BITS_UNPACKED");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(launch_tx_map(d_bits, bits_mode, h->dev.bps, n_symbols, reinterpret_cast<cf*>(d_sym),
+                          stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+int ofdm_tx_set_pilots(ofdm_tx* h, const int32_t* h_locations, int32_t n_pilots, float pilot_re, float pilot_im) {
+    if (!h || n_pilots < 0 || (n_pilots > 0 && !h_locations)) return fail(OFDM_ERR_INVALID, "ofdm_tx_set_pilots: bad argument");
+    const int K = h->dev.Kd + n_pilots;
+    if ((K & 1) || K > h->dev.nfft)
+        return fail(OFDM_ERR_INVALID, "num_data_bins + pilots = %d must be even and <= nfft", K);
+    std::vector<int> idx(size_t(n_pilots), 0);
+    for (int p = 0; p < n_pilots; ++p) {
+        const int loc = h_locations[p];
+        if (loc == 0 || loc < -(K / 2) || loc > K / 2)
+            return fail(OFDM_ERR_INVALID, "pilot location %d outside the occupied bins [-%d..-1, 1..%d]", loc, K / 2, K / 2);
+        idx[size_t(p)] = loc < 0 ? loc + K / 2 : K / 2 + loc - 1;
+    }
+    std::sort(idx.begin(), idx.end());
+    for (int p = 1; p < n_pilots; ++p)
+        if (idx[size_t(p)] == idx[size_t(p - 1)]) return fail(OFDM_ERR_INVALID, "pilot locations must be distinct");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->d_pilots) (void)hipFree(h->d_pilots);
+    h->d_pilots = nullptr;
+    h->n_pilots = 0;
+    if (n_pilots > 0) {
+        int rc = dev_alloc(&h->d_pilots, size_t(n_pilots));
+        if (rc != OFDM_OK) return rc;
+        HIP_TRY(hipMemcpy(h->d_pilots, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    h->n_pilots = n_pilots;
+    h->pilot_value = cf{pilot_re, pilot_im};
+    return OFDM_OK;
+}
+
+int ofdm_tx_grid(ofdm_tx* h, const float* d_sym, int64_t n_rows, float* d_grid, void* stream) {
+    if (!h || n_rows < 0 || (n_rows > 0 && (!d_sym || !d_grid))) return fail(OFDM_ERR_INVALID, "ofdm_tx_grid: bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    GridArgs a{};
+    a.sym = reinterpret_cast<const cf*>(d_sym);
+    a.n_rows = n_rows;
+    a.pilots = h->d_pilots;
+    a.n_pilots = h->n_pilots;
+    a.pilot_value = h->pilot_value;
+    a.grid = reinterpret_cast<cf*>(d_grid);
+    HIP_TRY(launch_tx_grid(h->dev, a, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+int ofdm_tx_ifft_cp(ofdm_tx* h, const float* d_in, int64_t n_rows, int32_t do_ifft, int32_t add_cp, float* d_out, void* stream) {
+    if (!h || n_rows < 0 || (n_rows > 0 && (!d_in || !d_out))) return fail(OFDM_ERR_INVALID, "ofdm_tx_ifft_cp: bad argument");
+    if (!do_ifft && !add_cp) return fail(OFDM_ERR_INVALID, "ofdm_tx_ifft_cp: nothing to do (do_ifft = add_cp = 0)");
+    if (n_rows > INT32_MAX) return fail(OFDM_ERR_INVALID, "batch too large");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    TimeArgs a{};
+    a.in = reinterpret_cast<const cf*>(d_in);
+    a.n_rows = n_rows;
+    a.do_ifft = do_ifft != 0;
+    a.do_cp = add_cp != 0;
+    a.out = reinterpret_cast<cf*>(d_out);
+    HIP_TRY(launch_tx_time(h->dev, a, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return OFDM_OK;
+}
+
+int64_t ofdm_tx_mux(ofdm_tx* h, const float* d_data, int64_t n_data_sym, float* d_out, void* stream) {
+    if (!h || n_data_sym < 0 || (n_data_sym > 0 && (!d_data || !d_out))) return fail(OFDM_ERR_INVALID, "ofdm_tx_mux: bad argument");
+    const TxDev& d = h->dev;
+    const int64_t full = n_data_sym / d.D, rem = n_data_sym % d.D;
+    const int64_t n_out = full * (d.S + d.D) + (rem ? d.S + rem : 0);
+    if (n_out == 0) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    MuxArgs a{};
+    a.sync_time = h->d_sync_time;
+    a.data = reinterpret_cast<const cf*>(d_data);
+    a.n_out_sym = n_out;
+    a.out = reinterpret_cast<cf*>(d_out);
+    HIP_TRY(launch_tx_mux(d, a, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    return n_out;
+}
+
+int ofdm_tx_get_sync_symbol(ofdm_tx* h, float* h_sync_time) {
+    if (!h || !h_sync_time) return fail(OFDM_ERR_INVALID, "ofdm_tx_get_sync_symbol: null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpy(h_sync_time, h->d_sync_time, size_t(h->dev.S) * h->dev.L * sizeof(cf), hipMemcpyDeviceToHost));
     return OFDM_OK;
 }
 

@@ -85,6 +85,27 @@ struct ModArgs {
     cf* iq;
     int64_t frame_stride;
 };
+// decomposed TX stages
+struct GridArgs {
+    const cf* sym;           // [n_rows][Kd]
+    int64_t n_rows;
+    const int* pilots;       // [n_pilots] ascending list indices into binsP(Kd + n_pilots), or null
+    int n_pilots;
+    cf pilot_value;
+    cf* grid;                // [n_rows][nfft]
+};
+struct TimeArgs {
+    const cf* in;            // do_ifft: [n_rows][nfft] grid rows; else [n_rows][nfft] time samples
+    int64_t n_rows;
+    int do_ifft, do_cp;
+    cf* out;                 // do_cp: [n_rows][L]; else [n_rows][nfft]
+};
+struct MuxArgs {
+    const cf* sync_time;     // [S][L]
+    const cf* data;          // [n_data_sym][L]
+    int64_t n_out_sym;
+    cf* out;                 // [n_out_sym][L]
+};
 struct ChanArgs {
     const cf* in;
     int64_t in_stride, in_len;
@@ -107,6 +128,12 @@ hipError_t launch_row_renorm(cf* eq, int Kd, int D, int n_frames, const int* tsr
 hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out, hipStream_t s);
 hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s);
 hipError_t launch_channel(const ChanArgs& a, hipStream_t s);
+hipError_t launch_tx_random_bits(uint64_t seed, uint64_t offset, uint8_t* out, int64_t n, hipStream_t s);
+hipError_t launch_tx_map(const uint8_t* bits, int bits_mode, int bps, int64_t n_sym, cf* out, hipStream_t s);
+hipError_t launch_tx_grid(const TxDev& tx, const GridArgs& a, hipStream_t s);
+hipError_t launch_tx_sync_grid(const TxDev& tx, cf* grid, hipStream_t s);
+hipError_t launch_tx_time(const TxDev& tx, const TimeArgs& a, hipStream_t s);
+hipError_t launch_tx_mux(const TxDev& tx, const MuxArgs& a, hipStream_t s);
 size_t rx_lds_bytes(int nfft);
 hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
                         hipStream_t s);

@@ -9,6 +9,29 @@
 
 namespace ofdm {
 
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0;
+        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = uint32_t(p1);
+        const uint32_t n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = uint32_t(p0);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
 __device__ __forceinline__ unsigned read_bits(const uint8_t* bits, int mode, int64_t bit0, int bps) {
     unsigned v = 0;
     if (mode == 2) {
@@ -41,6 +64,71 @@ __device__ __forceinline__ cf map_symbol(unsigned v, int bps) {
     const float s2i = (v & 8u) ? -1.f : 1.f, s4i = (v & 2u) ? -1.f : 1.f;
     const float s2q = (v & 4u) ? -1.f : 1.f, s4q = (v & 1u) ? -1.f : 1.f;
     return cf{si * (4.f - s2i * (2.f - s4i)) * s, sq * (4.f - s2q * (2.f - s4q)) * s};
+}
+
+// ---- shared pieces of the fused kernel and of the decomposed stage kernels: the SAME device functions, so that the chain
+// map -> grid -> IFFT -> CP equals the fused kernel bit for bit by construction.
+
+// value of resource-grid bin n of a DATA symbol (:150-183): list index i of bin n in binsP(K), K = Kd + n_pilots; pilots sit
+// at the list indices plist[0..n_pilots) (ascending), data symbols fill the remaining list entries in order.
+// A bin listed twice (K == N: bin N/2) keeps its later (positive-half) entry.  Returns false for an unused bin.
+__device__ __forceinline__ bool data_bin_index(int n, int K, int N, int& i) {
+    bool has = bin_neg(n, K, N, i);
+    int ip;
+    if (bin_pos(n, K, ip)) {
+        has = true;
+        i = ip;
+    }
+    return has;
+}
+
+// time-domain samples from the FFT of the conjugated grid row: ifft(X) = conj(fft(conj(X))) / N   (:199)
+template <int N>
+__device__ __forceinline__ void tx_time_from_fft(cf (&v)[Plan<N>::P]) {
+    const float invn = 1.f / float(N);
+#pragma unroll
+    for (int s = 0; s < Plan<N>::P; ++s) v[s] = cscale(cconj(v[s]), invn);
+}
+
+// x (register slot order: sample m = (t + T*j) + NC*kl in x[out_slot(j,kl)]) -> CP-extended, power-normalised symbol at `o`
+// (:200-218): energy and mean over the CP-extended symbol in one pass (CP samples count twice), then one scale.
+template <int N>
+__device__ __forceinline__ void tx_cp_norm_store(const TxDev& tx, const cf (&x)[Plan<N>::P], cf* lds, float* red, int t, cf* o,
+                                                 bool active) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T;
+    float e = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+        for (int kl = 0; kl < PL::RL; ++kl) {
+            const int m = (t + T * j) + PL::NC * kl;
+            const cf xv = x[out_slot<N>(j, kl)];
+            lds[m] = xv;
+            const float w = (m >= N - tx.cp) ? 2.f : 1.f;            // CP samples appear twice
+            e += w * cnorm2(xv);
+            sx += w * xv.x;
+            sy += w * xv.y;
+        }
+    }
+    e = symbol_sum<T>(e, red, t);
+    if constexpr (T > 64) wg_barrier();
+    sx = symbol_sum<T>(sx, red, t);
+    if constexpr (T > 64) wg_barrier();
+    sy = symbol_sum<T>(sy, red, t);
+    wg_barrier();
+    const float Lf = float(tx.L);
+    const float a1 = (e > 1e-30f) ? sqrtf(Lf / e) : 1.f;              // :204-205
+    const float mx = a1 * sx / Lf, my = a1 * sy / Lf;
+    const float var = a1 * a1 * e / Lf - (mx * mx + my * my);         // np.var(data_time) :213
+    const float scale = a1 / sqrtf(var);                              // :218
+    if (active) {
+        for (int j = t; j < tx.L; j += T) {
+            int m = j - tx.cp;
+            if (m < 0) m += N;
+            o[j] = cscale(lds[m], scale);
+        }
+    }
 }
 
 template <int N>
@@ -79,83 +167,138 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_modulate_kernel(TxDev tx, ModA
         if (active) {
             if (is_sync) {
                 // x_in = zchu[0:Ks] on used_bins_synch; synch_state never advances (:143-147)
-                if (bin_neg(n, tx.Ks, N, i)) X = tx.zc[i];
-                if (bin_pos(n, tx.Ks, i)) X = tx.zc[i];               // a bin listed twice keeps the later entry
+                if (data_bin_index(n, tx.Ks, N, i)) X = tx.zc[i];     // a bin listed twice keeps the later entry
             } else if (fbits) {
-                bool has = bin_neg(n, tx.Kd, N, i);
-                int ip;
-                if (bin_pos(n, tx.Kd, ip)) {
-                    has = true;
-                    i = ip;
-                }
-                if (has) X = map_symbol(read_bits(fbits, a.bits_mode, (ds * tx.Kd + i) * tx.bps, tx.bps), tx.bps);
+                if (data_bin_index(n, tx.Kd, N, i)) X = map_symbol(read_bits(fbits, a.bits_mode, (ds * tx.Kd + i) * tx.bps, tx.bps), tx.bps);
             }
         }
         v[n0] = cconj(X);
     }
     wg_fft<N>(v, lds, tw, w1tab, t);                                         // :199
     wg_barrier();
-    // natural-order time samples + energy / mean over the CP-extended symbol (:200-202,213)
-    float e = 0.f, sx = 0.f, sy = 0.f;
-    const float invn = 1.f / float(N);
-#pragma unroll
-    for (int j = 0; j < PL::C; ++j) {
-#pragma unroll
-        for (int kl = 0; kl < PL::RL; ++kl) {
-            const int m = (t + T * j) + PL::NC * kl;
-            const cf x = cscale(cconj(v[out_slot<N>(j, kl)]), invn);
-            lds[m] = x;
-            const float w = (m >= N - tx.cp) ? 2.f : 1.f;            // CP samples appear twice
-            e += w * cnorm2(x);
-            sx += w * x.x;
-            sy += w * x.y;
+    tx_time_from_fft<N>(v);
+    cf* o = a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L;
+    tx_cp_norm_store<N>(tx, v, lds, red, t, o, active);
+}
+
+// ------------------------------------------------------------------------------------------ decomposed stages
+// (random_bit_source -> ConstellationModulation -> OFDM_Modulation -> IFFT -> CyclicPrefix -> SynchDataMux,
+//  block names from LEGACY/gr-ofdm-tx/grc/RXtransmit_6.grc:701-975; the reference holds no code for them.)
+
+// one bit per byte from a counter-based generator: bit k of the stream = bit (k % 32) of word (k / 32) % 4 of
+// Philox4x32-10(counter = k / 128, key = seed).  Any [offset, offset + n) window can be produced independently.
+__global__ void __launch_bounds__(256) tx_random_bits_kernel(uint64_t seed, uint64_t offset, uint8_t* out, int64_t n) {
+    const uint64_t blk0 = offset >> 7;
+    const int64_t nblk = int64_t(((offset + uint64_t(n) + 127) >> 7) - blk0);
+    for (int64_t b = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; b < nblk; b += int64_t(gridDim.x) * blockDim.x) {
+        const uint64_t c = blk0 + uint64_t(b);
+        uint32_t w[4];
+        philox4x32_10(uint32_t(c), uint32_t(c >> 32), 0u, 0u, uint32_t(seed), uint32_t(seed >> 32), w);
+        for (int j = 0; j < 128; ++j) {
+            const uint64_t k = (c << 7) + uint64_t(j);
+            if (k >= offset && k < offset + uint64_t(n)) out[k - offset] = uint8_t((w[j >> 5] >> (j & 31)) & 1u);
         }
     }
-    e = symbol_sum<T>(e, red, t);
-    if constexpr (T > 64) wg_barrier();
-    sx = symbol_sum<T>(sx, red, t);
-    if constexpr (T > 64) wg_barrier();
-    sy = symbol_sum<T>(sy, red, t);
-    wg_barrier();
-    const float Lf = float(tx.L);
-    const float a1 = (e > 1e-30f) ? sqrtf(Lf / e) : 1.f;              // :204-205
-    const float mx = a1 * sx / Lf, my = a1 * sy / Lf;
-    const float var = a1 * a1 * e / Lf - (mx * mx + my * my);         // np.var(data_time) :213
-    const float scale = a1 / sqrtf(var);                              // :218
-    if (active) {
-        cf* o = a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L;
-        for (int j = t; j < tx.L; j += T) {
-            int m = j - tx.cp;
-            if (m < 0) m += N;
-            o[j] = cscale(lds[m], scale);
+}
+
+// ConstellationModulation: bits -> symbols, MSB-first per symbol (:156-178 / TS 36.211 for 16/64-QAM)
+__global__ void __launch_bounds__(256) tx_map_kernel(const uint8_t* bits, int bits_mode, int bps, int64_t n_sym, cf* out) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_sym; i += int64_t(gridDim.x) * blockDim.x)
+        out[i] = map_symbol(read_bits(bits, bits_mode, i * bps, bps), bps);
+}
+
+// OFDM_Modulation: rows of Kd symbols -> rows of N grid bins (data on binsP(Kd + n_pilots) minus the pilot entries)
+__global__ void __launch_bounds__(256) tx_grid_kernel(TxDev tx, GridArgs a) {
+    const int N = tx.nfft, K = tx.Kd + a.n_pilots;
+    const int64_t total = a.n_rows * N;
+    for (int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; g < total; g += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t row = g / N;
+        const int n = int(g - row * N);
+        cf X = cf{0.f, 0.f};
+        int i;
+        if (data_bin_index(n, K, N, i)) {
+            int before = 0;
+            bool is_pilot = false;
+            for (int p = 0; p < a.n_pilots; ++p) {
+                const int pi = a.pilots[p];
+                before += pi < i;
+                is_pilot |= pi == i;
+            }
+            X = is_pilot ? a.pilot_value : a.sym[row * tx.Kd + (i - before)];
+        }
+        a.grid[g] = X;
+    }
+}
+
+// rows [S][N] of the sync symbol's resource grid: zchu[0:Ks] on binsP(Ks), the same segment for every sync symbol (:143-147)
+__global__ void __launch_bounds__(256) tx_sync_grid_kernel(TxDev tx, cf* grid) {
+    const int N = tx.nfft;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < tx.S * N; g += gridDim.x * blockDim.x) {
+        const int n = g % N;
+        int i;
+        grid[g] = data_bin_index(n, tx.Ks, N, i) ? tx.zc[i] : cf{0.f, 0.f};
+    }
+}
+
+// IFFT and/or CyclicPrefix on rows:  IFFT: [N] grid bins -> [N] time samples;  CP: [N] time samples -> [L] CP-extended,
+// power-normalised;  both: the fused symbol synthesis.
+template <int N, bool DO_IFFT, bool DO_CP>
+__global__ void __launch_bounds__(Plan<N>::WG) tx_time_kernel(TxDev tx, TimeArgs a) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    const cf* w1tab = wg_init_w1<N>(smem, tx.tw, tid);
+    const int64_t row = int64_t(blockIdx.x) * PL::SLOTS + slot;
+    const bool active = row < a.n_rows;
+    const cf* in = a.in + (active ? row : 0) * N;
+    cf v[P];
+    if constexpr (DO_IFFT) {
+        LaneTwiddles<N> tw;
+        load_twiddles<N>(tw, tx.tw, t);
+#pragma unroll
+        for (int n0 = 0; n0 < P; ++n0) v[n0] = active ? cconj(in[t + T * n0]) : cf{0.f, 0.f};
+        wg_fft<N>(v, lds, tw, w1tab, t);
+        wg_barrier();
+        tx_time_from_fft<N>(v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+            for (int kl = 0; kl < PL::RL; ++kl)
+                v[out_slot<N>(j, kl)] = active ? in[(t + T * j) + PL::NC * kl] : cf{0.f, 0.f};
         }
     }
+    if constexpr (DO_CP) {
+        tx_cp_norm_store<N>(tx, v, lds, red, t, a.out + (active ? row : 0) * tx.L, active);
+    } else {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+                for (int kl = 0; kl < PL::RL; ++kl) a.out[row * N + (t + T * j) + PL::NC * kl] = v[out_slot<N>(j, kl)];
+            }
+        }
+    }
+}
+
+// SynchDataMux: S sync symbols in front of every D data symbols (symbols are L samples)
+__global__ void __launch_bounds__(256) tx_mux_kernel(TxDev tx, MuxArgs a) {
+    const int L = tx.L, SD = tx.S + tx.D;
+    const int64_t s_out = blockIdx.y;
+    const int64_t pat = s_out / SD;
+    const int r = int(s_out - pat * SD);
+    const cf* src = r < tx.S ? a.sync_time + int64_t(r) * L : a.data + (pat * tx.D + (r - tx.S)) * L;
+    cf* dst = a.out + s_out * L;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < L; j += gridDim.x * blockDim.x) dst[j] = src[j];
 }
 
 // ------------------------------------------------------------------------------------------ channel
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = uint64_t(0xD2511F53u) * c0;
-        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
-        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = uint32_t(p1);
-        const uint32_t n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = uint32_t(p0);
-        c0 = n0;
-        c1 = n1;
-        c2 = n2;
-        c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0;
-    out[1] = c1;
-    out[2] = c2;
-    out[3] = c3;
-}
-
 __global__ void __launch_bounds__(256) channel_kernel(ChanArgs a) {
     const int frame = blockIdx.y;
     const cf* in = a.in + int64_t(frame) * a.in_stride;
@@ -249,6 +392,72 @@ hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s) 
         case 4096: return launch_mod_n<4096>(tx, a, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_tx_random_bits(uint64_t seed, uint64_t offset, uint8_t* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t nblk = (n + 127) / 128 + 1;
+    hipLaunchKernelGGL(tx_random_bits_kernel, dim3(unsigned(std::min<int64_t>((nblk + 255) / 256, 4096))), dim3(256), 0, s, seed, offset, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_tx_map(const uint8_t* bits, int bits_mode, int bps, int64_t n_sym, cf* out, hipStream_t s) {
+    if (n_sym <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tx_map_kernel, dim3(unsigned(std::min<int64_t>((n_sym + 255) / 256, 8192))), dim3(256), 0, s, bits, bits_mode, bps, n_sym, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tx_grid(const TxDev& tx, const GridArgs& a, hipStream_t s) {
+    if (a.n_rows <= 0) return hipSuccess;
+    const int64_t total = a.n_rows * tx.nfft;
+    hipLaunchKernelGGL(tx_grid_kernel, dim3(unsigned(std::min<int64_t>((total + 255) / 256, 16384))), dim3(256), 0, s, tx, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tx_sync_grid(const TxDev& tx, cf* grid, hipStream_t s) {
+    hipLaunchKernelGGL(tx_sync_grid_kernel, dim3(unsigned((tx.S * tx.nfft + 255) / 256)), dim3(256), 0, s, tx, grid);
+    return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_time_n(const TxDev& tx, const TimeArgs& a, hipStream_t s) {
+    const unsigned grid = unsigned((a.n_rows + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    if (grid == 0) return hipSuccess;
+    if (a.do_ifft && a.do_cp)
+        hipLaunchKernelGGL((tx_time_kernel<N, true, true>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, tx, a);
+    else if (a.do_ifft)
+        hipLaunchKernelGGL((tx_time_kernel<N, true, false>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, tx, a);
+    else if (a.do_cp)
+        hipLaunchKernelGGL((tx_time_kernel<N, false, true>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, tx, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_tx_time(const TxDev& tx, const TimeArgs& a, hipStream_t s) {
+    switch (tx.nfft) {
+        case 64: return launch_time_n<64>(tx, a, s);
+        case 128: return launch_time_n<128>(tx, a, s);
+        case 256: return launch_time_n<256>(tx, a, s);
+        case 512: return launch_time_n<512>(tx, a, s);
+        case 1024: return launch_time_n<1024>(tx, a, s);
+        case 2048: return launch_time_n<2048>(tx, a, s);
+        case 4096: return launch_time_n<4096>(tx, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_tx_mux(const TxDev& tx, const MuxArgs& a, hipStream_t s) {
+    const int SD = tx.S + tx.D;
+    const int64_t per_launch = int64_t(65535 / SD) * SD;          // blockIdx.y = output symbol, whole patterns per launch
+    for (int64_t s0 = 0; s0 < a.n_out_sym; s0 += per_launch) {
+        const int64_t cnt = std::min<int64_t>(per_launch, a.n_out_sym - s0);
+        MuxArgs b = a;
+        b.out = a.out + s0 * tx.L;
+        b.data = a.data + (s0 / SD) * tx.D * tx.L;
+        hipLaunchKernelGGL(tx_mux_kernel, dim3(unsigned((tx.L + 255) / 256), unsigned(cnt)), dim3(256), 0, s, tx, b);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_channel(const ChanArgs& a, hipStream_t s) {

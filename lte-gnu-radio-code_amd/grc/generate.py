@@ -13,6 +13,7 @@ import os
 import yaml
 
 CPLX_IN = [dict(domain="stream", dtype="complex")]
+BYTE_IN = [dict(domain="stream", dtype="byte")]
 
 RX_PARAMS = [("num_ofdm_symb", "OFDM symbols per buffer", "int"), ("nfft", "FFT size", "int"),
              ("cp_len", "Cyclic prefix length", "int"), ("num_synch_bins", "Sync bins", "int"),
@@ -26,8 +27,9 @@ BLOCKS = [
          cls="SynchAndChanEst",
          params=RX_PARAMS + [("scale_factor_gate", "Correlation gate", "float")] + FILE_PARAMS +
          [("diagnostics", "Diagnostics", "bool"), ("genie", "Genie", "bool"), ("channel", "Channel type (genie only)", "string")],
+         # like the reference's template, `channel` is declared but not passed (the constructor defaults it)
          make_args=["num_ofdm_symb", "nfft", "cp_len", "num_synch_bins", "synch_dat", "num_data_bins", "snr",
-                    "scale_factor_gate", "directory_name", "file_name_cest", "diagnostics", "genie", "channel"],
+                    "scale_factor_gate", "directory_name", "file_name_cest", "diagnostics", "genie"],
          inputs=CPLX_IN, outputs=CPLX_IN),
     dict(id="utsa_ofdm_TxSignalTransmitter", label="TxSignalTransmitter (MI355X)", category="[utsa_ofdm]",
          module="utsa_ofdm", cls="TxSignalTransmitter", params=TX_PARAMS,
@@ -66,6 +68,25 @@ BLOCKS = [
          params=[("case", "Case Number", "int"), ("fo_range", "F Offset Range", "raw"), ("directory_name", "Directory Path", "string"),
                  ("file_name_cest", "Var: Chan Est -- File Name", "string"), ("diagnostics", "Diagnostics", "int")],
          make_args=["case", "fo_range", "directory_name", "file_name_cest", "diagnostics"], inputs=CPLX_IN, outputs=CPLX_IN),
+    # ---- the decomposed live transmitter: block ids and parameter ids as the reference's flowgraph uses them
+    # (LEGACY/gr-ofdm-tx/grc/RXtransmit_6.grc:701-975); the reference ships no block description for them
+    dict(id="txOFDM_random_bit_source", label="Random Bit Source (MI355X)", category="[txOFDM]", module="txOFDM",
+         cls="random_bit_source", params=[], make_args=[], inputs=None, outputs=BYTE_IN),
+    dict(id="txOFDM_ConstellationModulation", label="Constellation Modulation (MI355X)", category="[txOFDM]", module="txOFDM",
+         cls="ConstellationModulation", params=[("modulation", "Modulation", "string")], make_args=["modulation"],
+         inputs=BYTE_IN, outputs=CPLX_IN),
+    dict(id="txOFDM_OFDM_Modulation", label="OFDM Modulation (MI355X)", category="[txOFDM]", module="txOFDM",
+         cls="OFDM_Modulation", params=[("fft_size", "FFT Size", "int"), ("pilot_locations", "Pilot Locations", "raw")],
+         make_args=["fft_size", "pilot_locations"], inputs=CPLX_IN, outputs=CPLX_IN),
+    dict(id="txOFDM_IFFT", label="IFFT (MI355X)", category="[txOFDM]", module="txOFDM", cls="IFFT",
+         params=[("fft_size", "FFT Size", "int")], make_args=["fft_size"], inputs=CPLX_IN, outputs=CPLX_IN),
+    dict(id="txOFDM_CyclicPrefix", label="Cyclic Prefix (MI355X)", category="[txOFDM]", module="txOFDM", cls="CyclicPrefix",
+         params=[("fft_size", "FFT Size", "int"), ("cp_size", "CP Size", "int")], make_args=["fft_size", "cp_size"],
+         inputs=CPLX_IN, outputs=CPLX_IN),
+    dict(id="txOFDM_SynchDataMux", label="Synch / Data Mux (MI355X)", category="[txOFDM]", module="txOFDM", cls="SynchDataMux",
+         params=[("fft_size", "FFT Size", "int"), ("cp_size", "CP Size", "int"), ("prime_no", "Zadoff-Chu root", "int"),
+                 ("synch_every", "Data symbols per sync symbol", "int"), ("synch_length", "Sync bins", "int")],
+         make_args=["fft_size", "cp_size", "prime_no", "synch_every", "synch_length"], inputs=CPLX_IN, outputs=CPLX_IN),
 ]
 
 
@@ -82,15 +103,23 @@ def block_yaml(b):
     return yaml.safe_dump(doc, sort_keys=False)
 
 
+def write_all(out_dir):
+    os.makedirs(out_dir, exist_ok=True)
+    names = []
+    for b in BLOCKS:
+        names.append(b["id"] + ".block.yml")
+        with open(os.path.join(out_dir, names[-1]), "w") as f:
+            f.write(block_yaml(b))
+    return names
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", required=True)
+    ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)),
+                    help="directory on GRC's block path (default: next to this script, where the generated files are committed)")
     args = ap.parse_args()
-    os.makedirs(args.out, exist_ok=True)
-    for b in BLOCKS:
-        with open(os.path.join(args.out, b["id"] + ".block.yml"), "w") as f:
-            f.write(block_yaml(b))
-        print("wrote", b["id"] + ".block.yml")
+    for n in write_all(args.out):
+        print("wrote", n)
 
 
 if __name__ == "__main__":

@@ -110,6 +110,13 @@ PROTOTYPES = {
     "ofdm_tx_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_tx_modulate_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
                                           C.c_int64, C.c_void_p]),
+    "ofdm_tx_random_bits": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ofdm_tx_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ofdm_tx_set_pilots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float]),
+    "ofdm_tx_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ofdm_tx_ifft_cp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ofdm_tx_mux": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ofdm_tx_get_sync_symbol": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ofdm_channel_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
 }

@@ -314,6 +314,37 @@ class TxEngine:
         check(self.lib.ofdm_tx_modulate_frames(self._h, ptr(d_bits), int(bits_mode), int(n_frames), int(n_sym),
                                                ptr(d_iq), int(frame_stride), ptr(stream)))
 
+    # ---- decomposed stages (device buffers)
+    def random_bits(self, seed, offset, d_bits, n_bits, stream=None):
+        check(self.lib.ofdm_tx_random_bits(self._h, int(seed), int(offset), ptr(d_bits), int(n_bits), ptr(stream)))
+
+    def map(self, d_bits, n_symbols, d_sym, bits_mode=BITS_UNPACKED, stream=None):
+        check(self.lib.ofdm_tx_map(self._h, ptr(d_bits), int(bits_mode), int(n_symbols), ptr(d_sym), ptr(stream)))
+
+    def set_pilots(self, locations, value=1.0 + 0.0j):
+        loc = np.ascontiguousarray(list(locations), dtype=np.int32)
+        check(self.lib.ofdm_tx_set_pilots(self._h, ptr(loc) if loc.size else None, int(loc.size), float(np.real(value)), float(np.imag(value))))
+
+    def grid(self, d_sym, n_rows, d_grid, stream=None):
+        check(self.lib.ofdm_tx_grid(self._h, ptr(d_sym), int(n_rows), ptr(d_grid), ptr(stream)))
+
+    def ifft_cp(self, d_in, n_rows, d_out, do_ifft=True, add_cp=True, stream=None):
+        check(self.lib.ofdm_tx_ifft_cp(self._h, ptr(d_in), int(n_rows), int(bool(do_ifft)), int(bool(add_cp)), ptr(d_out), ptr(stream)))
+
+    def mux_symbols(self, n_data_sym: int) -> int:
+        c = self.cfg
+        full, rem = divmod(int(n_data_sym), c.synch_D)
+        return full * (c.synch_S + c.synch_D) + (c.synch_S + rem if rem else 0)
+
+    def mux(self, d_data, n_data_sym, d_out, stream=None) -> int:
+        return int(check(self.lib.ofdm_tx_mux(self._h, ptr(d_data), int(n_data_sym), ptr(d_out), ptr(stream))))
+
+    def sync_symbol(self) -> np.ndarray:
+        c = self.cfg
+        out = np.zeros((c.synch_S, c.nfft + c.cp_len), np.complex64)
+        check(self.lib.ofdm_tx_get_sync_symbol(self._h, ptr(out)))
+        return out
+
     def channel(self, d_in, n_frames, in_stride, in_len, d_taps, n_taps, d_out, out_stride, out_len,
                 noise_var=0.0, seed=0, per_frame_taps=False, stream=None):
         check(self.lib.ofdm_channel_apply(self._h, ptr(d_in), int(n_frames), int(in_stride), int(in_len), ptr(d_taps),

@@ -234,20 +234,94 @@ def tx_grid(bits: np.ndarray, nfft: int, num_synch_bins: int, num_data_bins: int
     return grid
 
 
+def tx_cp_norm(x: np.ndarray, cp_len: int) -> np.ndarray:
+    """One symbol's time samples -> CP-extended, power-normalised symbol (TX:200-218)."""
+    t = np.concatenate((x[-cp_len:], x)) if cp_len > 0 else x.copy()         # TX:200-201
+    e = abs(np.dot(t, np.conj(t)))                                           # TX:202
+    if e > 1e-30:                                                            # TX:204
+        t = t * np.sqrt(len(t) / e)                                          # TX:205-207
+    p = np.var(t)                                                            # TX:213
+    return t * (1 / np.sqrt(p))                                              # TX:218
+
+
 def tx_symbol_synth(grid: np.ndarray, cp_len: int) -> np.ndarray:
     """IFFT + CP + power normalisation, symbol by symbol (TX:189-218). Returns flat IQ."""
     n_sym, nfft = grid.shape
     L = nfft + cp_len
     out = np.zeros(n_sym * L, dtype=np.complex128)
     for s in range(n_sym):
-        x = np.fft.ifft(grid[s], nfft)                                   # TX:199
-        t = np.concatenate((x[-cp_len:], x)) if cp_len > 0 else x.copy()  # TX:200-201
-        e = abs(np.dot(t, np.conj(t)))                                   # TX:202
-        if e > 1e-30:                                                    # TX:204
-            t = t * np.sqrt(len(t) / e)                                  # TX:205-207
-        p = np.var(t)                                                    # TX:213
-        out[s * L:(s + 1) * L] = t * (1 / np.sqrt(p))                    # TX:218
+        out[s * L:(s + 1) * L] = tx_cp_norm(np.fft.ifft(grid[s], nfft), cp_len)     # TX:199
     return out
+
+
+# ---- the decomposed transmitter (block names only in LEGACY/gr-ofdm-tx/grc/RXtransmit_6.grc:701-975; no reference code).
+# Each stage is the matching slice of TX:135-218; chained with no pilots they ARE tx_modulate (asserted in the tests).
+# Pilots and the counter-based bit source are this project's own definitions: parity unpinned.
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on uint32 arrays; returns the four output words."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & 0xFFFFFFFF for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0 = (k0 + W0) & MASK
+        k1 = (k1 + W1) & MASK
+    return c0, c1, c2, c3
+
+
+def random_bits(seed: int, offset: int, n: int) -> np.ndarray:
+    """Bits [offset, offset+n) of the random_bit_source stream: bit k = bit (k%32) of word (k/32)%4 of
+    Philox4x32-10(counter = k/128, key = seed)  (include/ofdm_mi355x.h: ofdm_tx_random_bits)."""
+    k = np.arange(offset, offset + n, dtype=np.uint64)
+    blk = k >> np.uint64(7)
+    ub, inv = np.unique(blk, return_inverse=True)
+    w = np.stack(philox4x32_10(ub & np.uint64(0xFFFFFFFF), ub >> np.uint64(32), 0 * ub, 0 * ub, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    j = (k & np.uint64(127)).astype(np.int64)
+    words = w[j >> 5, inv]
+    return ((words >> (j & 31).astype(np.uint64)) & np.uint64(1)).astype(np.uint8)
+
+
+def tx_stage_grid(symbols: np.ndarray, nfft: int, num_data_bins: int, pilot_locations=(), pilot_value=1.0 + 0j) -> np.ndarray:
+    """OFDM_Modulation: rows of Kd symbols -> rows of nfft bins.  Occupied bins = bins_p(Kd + n_pilots) (TX:135-139), the
+    signed offsets `pilot_locations` carry `pilot_value`, data fill the remaining occupied bins in list order (TX:182-183)."""
+    sym = np.asarray(symbols).reshape(-1, num_data_bins)
+    K = num_data_bins + len(pilot_locations)
+    occ = bins_p(K, nfft)
+    pil = {(int(p) + nfft) % nfft for p in pilot_locations}
+    assert len(pil) == len(pilot_locations) and all(b in set(occ.tolist()) for b in pil)
+    data_bins = np.array([b for b in occ if b not in pil], dtype=np.int64)
+    grid = np.zeros((sym.shape[0], nfft), dtype=np.complex128)
+    grid[:, data_bins] = sym
+    if pil:
+        grid[:, sorted(pil)] = pilot_value
+    return grid
+
+
+def tx_stage_ifft(grid: np.ndarray) -> np.ndarray:
+    """IFFT: one numpy.fft.ifft per row (TX:199)."""
+    return np.fft.ifft(np.asarray(grid), axis=1)
+
+
+def tx_stage_cp(time_rows: np.ndarray, cp_len: int) -> np.ndarray:
+    """CyclicPrefix: CP + power normalisation per row (TX:200-218)."""
+    return np.stack([tx_cp_norm(r, cp_len) for r in np.asarray(time_rows)])
+
+
+def tx_stage_mux(data_rows: np.ndarray, nfft: int, cp_len: int, prime_no: int, synch_every: int, synch_length: int) -> np.ndarray:
+    """SynchDataMux: one ZC sync symbol (root prime_no on bins_p(synch_length), ZC:13-30, through the same IFFT + CP +
+    normalisation) in front of every `synch_every` data symbols; a trailing partial group keeps its sync symbol."""
+    g = np.zeros(nfft, dtype=np.complex128)
+    g[bins_p(synch_length, nfft)] = zadoff_chu(synch_length, prime_no)
+    sync = tx_cp_norm(np.fft.ifft(g, nfft), cp_len)
+    rows = []
+    for i, r in enumerate(np.asarray(data_rows)):
+        if i % synch_every == 0:
+            rows.append(sync)
+        rows.append(r)
+    return np.stack(rows) if rows else np.zeros((0, nfft + cp_len), dtype=np.complex128)
 
 
 def tx_modulate(bits, nfft, cp_len, num_synch_bins, num_data_bins, n_sym,
