@@ -477,7 +477,7 @@ def main(argv=None):
                 ent = json.load(open(os.path.join(ROOT, "profiles", tf))).get(key)
             except Exception:
                 ent = None
-            if ent and ent.get("kernel_source_sha") == sha and ent.get("data_symbols_per_launch") == dsym:
+            if isinstance(ent, dict) and ent.get("kernel_source_sha") == sha and ent.get("data_symbols_per_launch") == dsym:
                 traffic = int(ent["hbm_bytes_per_launch_mean"])
                 phys_read = ent["hbm_read_bytes_per_launch_mean"] / (dm * 1e-3) / 1e9
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel source, sha %s, kernel %s)" % (tf, sha, ent.get("kernel"))

@@ -25,15 +25,59 @@ namespace ofdm {
 
 // BitRecovery's hard decision for float32 inputs (oracle/ofdm_oracle.py:demap_hard has the derivation):
 //   QPSK axis bit = 1  iff  -sqrt2 <= x < 0  or  x > sqrt2   ==  (x < 0) xor (|x| > sqrt2_f32)
+// valid whenever NEITHER coordinate of the symbol is exactly zero.
 __device__ __forceinline__ unsigned qpsk_axis_bit(float x) {
     constexpr float t = 1.41421354f;   // largest float32 below sqrt(2)
     return unsigned(x < 0.f) ^ unsigned(fabsf(x) > t);
+}
+
+// A symbol ON an axis (or at the origin) is equidistant, in exact arithmetic, from two (four) constellation points.  The
+// reference decides such ties by what its fp64 arithmetic happens to produce (BitRecovery.py:45-52,82-98,105-157), so this
+// slow path repeats that arithmetic literally, in double:
+//   CDAT  = exp(j 2pi/8 [1,-1,3,5]) as float64 (:45-52) -- not symmetric in the last bit: (bcd,bcc) (bcd,-bcc) (-bcc,bcd) (-bce,-bcc)
+//   dist  = |z - CDAT_k| the way NumPy's AVX-512 complex-abs kernel forms it (the recorded reference run, tests/golden/
+//           ref_bitrecovery.npz):  max * sqrt(fma(r, r, 1)), r = min / max   -- all correctly rounded IEEE operations
+//   k*    = first arg-min (:87);  e = z - CDAT_k* (:93-98)
+//   quadrant of z in the reference's order ++, -+, --, +- with >= / <= (first match wins, :106-125) picks which of the
+//           metrics -f/2 |e| and -f/2 (K - |e|), K = 1.414213562373095 (:57), is llrp0 / llrp1
+//   bit   = int(0.5 (sign(llrp1 - llrp0) + 1)) (:155-156)  ==  [ x(llrp1) < x(llrp0) ]  with x = |e| or K - |e|
+//           (the common factor -f/2 is negative; the two x differ by 0, 2 or 4 ulp on a tie, so the products never collapse)
+__device__ __noinline__ unsigned qpsk_bits_on_axis(float zx, float zy) {
+    constexpr double A = 0x1.6a09e667f3bcdp-1, B = 0x1.6a09e667f3bccp-1, Cc = 0x1.6a09e667f3bcep-1;
+    const double cx[4] = {A, A, -B, -Cc};
+    const double cy[4] = {B, -B, A, -B};
+    constexpr double K = 0x1.6a09e667f3bccp+0;             // the literal 1.414213562373095
+    const double x = double(zx), y = double(zy);
+    int kbest = 0;
+    double dbest = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double ax = fabs(x - cx[k]), ay = fabs(y - cy[k]);
+        const double mx = fmax(ax, ay), mn = fmin(ay, ax);
+        const double r = mn / mx;                           // mx >= 0.29: no 0/0 here
+        const double d = sqrt(fma(r, r, 1.0)) * mx;
+        if (k == 0 || d < dbest) {
+            dbest = d;
+            kbest = k;
+        }
+    }
+    const double ex = fabs(x - cx[kbest]), ey = fabs(y - cy[kbest]);
+    const bool q1 = x >= 0.0 && y >= 0.0;
+    const bool q2 = !q1 && x <= 0.0 && y >= 0.0;
+    const bool q3 = !q1 && !q2 && x <= 0.0 && y <= 0.0;
+    const bool q4 = !q1 && !q2 && !q3 && x >= 0.0 && y <= 0.0;
+    const bool re_pos = q1 || q4, im_pos = q1 || q2;
+    const double fr = K - ex, fi = K - ey;
+    const unsigned b0 = re_pos ? (fr < ex) : (ex < fr);
+    const unsigned b1 = im_pos ? (fi < ey) : (ey < fi);
+    return (b0 << 1) | b1;
 }
 
 // bits of one symbol, b0 in the most significant of MOD bits
 template <int MOD>
 __device__ __forceinline__ unsigned hard_bits(cf z) {
     if constexpr (MOD == 2) {
+        if (z.x == 0.f || z.y == 0.f) return qpsk_bits_on_axis(z.x, z.y);      // NaN compares false: closed form below
         return (qpsk_axis_bit(z.x) << 1) | qpsk_axis_bit(z.y);
     } else if constexpr (MOD == 1) {
         return z.x > 0.f;
@@ -105,6 +149,14 @@ __device__ __forceinline__ unsigned pack4(const cf (&z)[4]) {
 #undef OFDM_Q64
     } else if constexpr (MOD == 2) {
         constexpr float t = 1.41421354f;             // largest float32 below sqrt(2): BitRecovery's outlier edge
+        // a coordinate that is exactly zero (a tie of the reference's nearest-point search) takes the literal path
+        if (z[0].x * z[0].y * z[1].x * z[1].y == 0.f || z[2].x * z[2].y * z[3].x * z[3].y == 0.f) {
+            bool tie = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tie |= (z[e].x == 0.f) | (z[e].y == 0.f);
+            if (tie)
+                return (((((hard_bits<2>(z[0]) << 2) | hard_bits<2>(z[1])) << 2) | hard_bits<2>(z[2])) << 2) | hard_bits<2>(z[3]);
+        }
         unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
         // two symbols per group: bit = (x < 0) xor (|x| > sqrt2)
 #define OFDM_QPSK2(RE0, IM0, RE1, IM1)                     \

@@ -87,9 +87,9 @@ def demap_hard(z: np.ndarray, modulation: str) -> np.ndarray:
         b0 = 1  iff  -sqrt2 <= Re z < 0   or   Re z > sqrt2        (same for b1 with Im z)
     i.e. the sign rule PLUS the reference's outlier flip beyond |x| > sqrt(2) (its "far" metric
     K-|e| goes negative there).  For float32 inputs the edges are exactly +-SQRT2_F32.  This closed
-    form equals ``bit_recovery(z)[0]`` whenever |Re z|, |Im z| > 1e-15; on (near-)zero coordinates
-    the reference's own outcome hinges on last-bit fp64 rounding of its nearest-point search and LLR
-    products, so no parity is claimed there (the closed form then returns 0).
+    form equals ``bit_recovery(z)[0]`` whenever neither coordinate is exactly zero; a symbol ON an axis is a
+    tie of the reference's nearest-point search, decided by the last bit of its fp64 arithmetic: those
+    symbols are handed to ``bit_recovery`` (the literal restatement) here as well.
     16QAM / 64QAM: 3GPP TS 36.211 7.1 decision regions (extension, unpinned).
     """
     z = np.asarray(z).astype(np.complex64).ravel()
@@ -100,7 +100,11 @@ def demap_hard(z: np.ndarray, modulation: str) -> np.ndarray:
         t = SQRT2_F32
         b0 = ((re < 0) & (re >= -t)) | (re > t)
         b1 = ((im < 0) & (im >= -t)) | (im > t)
-        return np.stack([b0, b1], axis=1).astype(np.uint8).ravel()
+        out = np.stack([b0, b1], axis=1).astype(np.uint8)
+        tie = np.nonzero((re == 0) | (im == 0))[0]
+        if tie.size:        # the hard bit of a tie does not depend on the other symbols of the buffer (sigma only scales it)
+            out[tie] = bit_recovery(np.concatenate([z[tie], np.array([1 + 1j], np.complex64)]))[0][:-2].reshape(-1, 2)
+        return out.ravel()
     if modulation == "16QAM":
         t = np.float32(2.0 / np.sqrt(10.0))
         return np.stack([re < 0, im < 0, np.abs(re) > t, np.abs(im) > t], axis=1).astype(np.uint8).ravel()
@@ -112,6 +116,18 @@ def demap_hard(z: np.ndarray, modulation: str) -> np.ndarray:
     raise ValueError(modulation)
 
 
+def _cabs_avx512(a: float, b: float) -> float:
+    """|a + jb| as NumPy's AVX-512 kernel forms it (numpy/_core/src/umath/loops_*: avx512_cabsolute): every step one
+    correctly rounded IEEE operation."""
+    from fractions import Fraction
+    a, b = abs(float(a)), abs(float(b))
+    mx, mn = max(a, b), min(b, a)
+    if not np.isfinite(mx) or mx == 0.0:
+        return mx
+    r = mn / mx
+    return float(np.sqrt(np.float64(float(Fraction(r) * Fraction(r) + 1)))) * mx
+
+
 def bit_recovery(z: np.ndarray):
     """Literal restatement of BitRecovery.work (BR:66-157) for QPSK.
 
@@ -121,8 +137,15 @@ def bit_recovery(z: np.ndarray):
     n = len(z)
     cdat = _QPSK_POINTS
     zobs = z[:, None] - cdat[None, :]                       # BR:82-86
-    dminind = np.argmin(np.abs(zobs), axis=1)               # BR:87
-    dmin = np.min(np.abs(zobs), axis=1)                     # BR:88
+    dist = np.abs(zobs)
+    # A symbol with an exactly-zero coordinate is, in exact arithmetic, equidistant from two (four) points: the reference's
+    # arg-min there is decided by the last bit of np.abs.  The recorded reference run (tests/golden/ref_bitrecovery.npz) used
+    # NumPy's AVX-512 complex-abs kernel, |a+jb| = max*sqrt(fma(r,r,1)), r = min/max; hosts without AVX-512 take libm's hypot and
+    # can differ in that last bit.  The tie rows are therefore restated with that formula explicitly (exact fma by rationals).
+    for i in np.nonzero((z.real == 0) | (z.imag == 0))[0]:
+        dist[i] = [_cabs_avx512(v.real, v.imag) for v in zobs[i]]
+    dminind = np.argmin(dist, axis=1)                       # BR:87
+    dmin = np.min(dist, axis=1)                             # BR:88
     ez = z - cdat[dminind]                                  # BR:93-98
     sigma = 0.7071067811865476 * np.mean(np.abs(dmin))      # BR:102
     dfact = 1.0 / (sigma * sigma)                           # BR:103

@@ -73,10 +73,14 @@ def test_chained_stages_equal_the_fused_kernel_bit_for_bit(om, N, cp, Kd, mod, n
     assert np.array_equal(st["out"], ref_gpu)                                   # bit for bit
     assert np.array_equal(st["cp"], st["fused_time"])                           # IFFT and CP in one launch == two launches
     # every stage against its oracle counterpart
-    assert np.array_equal(st["sym"], orc.map_bits(bits, mod).astype(np.complex64))
+    sym = orc.map_bits(bits, mod)
+    if mod in ("BPSK", "QPSK"):
+        assert np.array_equal(st["sym"], sym.astype(np.complex64))
+    assert relerr(st["sym"], sym) < 2e-7                     # 16/64-QAM levels are formed in fp32 on the device (1 ulp)
     if Kd < N:
-        g = orc.tx_stage_grid(orc.map_bits(bits, mod), N, Kd)
-        assert np.array_equal(st["grid"], g.astype(np.complex64))
+        g = orc.tx_stage_grid(sym, N, Kd)
+        assert np.array_equal(st["grid"] != 0, g != 0) and relerr(st["grid"], g) < 2e-7
+        assert np.array_equal(st["grid"][:, orc.bins_p(Kd, N)].ravel(), st["sym"])
         assert relerr(st["time"], orc.tx_stage_ifft(g)) < TOL
         assert relerr(st["cp"], orc.tx_stage_cp(orc.tx_stage_ifft(g), cp)) < TOL
         assert relerr(st["out"], orc.tx_modulate(bits, N, cp, Ks, Kd, n_sym, modulation=mod)) < TOL
