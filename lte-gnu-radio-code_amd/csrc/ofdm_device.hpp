@@ -105,11 +105,11 @@ __device__ __forceinline__ void symbol_argmax(float& val, int& idx, float* redv,
 }
 
 // ------------------------------------------------------------------------------ workgroup LDS carve
-// [ SLOTS x ( exchange/staging region | 16 dwords reduction scratch ) | pass-1 twiddle table ]
+// [ SLOTS x ( exchange/staging region | 24 dwords reduction scratch ) | pass-1 twiddle table ]
 template <int N>
 struct WgLds {
     static constexpr int ELEMS = Plan<N>::LDS_ELEMS + (Plan<N>::LDS_ELEMS & 1);
-    static constexpr int RED_CF = 8;                                  // 8 cf = 16 dwords of scratch
+    static constexpr int RED_CF = 12;                                 // 12 cf = 24 dwords of scratch (16 reductions + 8 spare)
     static constexpr int STRIDE = ELEMS + RED_CF;                     // cf units, even -> 16 B aligned
     static constexpr int W1_ELEMS = Plan<N>::THREE ? 16 * Plan<N>::RL : 0;
     static constexpr size_t BYTES = (size_t(STRIDE) * Plan<N>::SLOTS + W1_ELEMS) * sizeof(cf);

@@ -18,11 +18,14 @@ namespace ofdm {
 // One sync trial P of one frame (SynchAndChanEst.py:145-164).  On return: Z (per-lane bins, register
 // slot order) = sum over the S sync symbols of Y[k]*conj(zc), zdup = negative-half part of a bin that
 // is listed twice (K == N only), p_est, m = max|del_mat|, dhat = argmax lag.
-template <int N, class TW>
+// KEEP > 0 (scan kernel, S == 1): additionally returns, per lane, the COMPLEX lag correlations c[a] for a = t + T*q, q < KEEP
+// (ukeep), the in-band energy sum |Y|^2 (ekeep) and -- in red[16..19] -- the DC and Nyquist bins of the window's FFT.
+template <int N, class TW, int KEEP = 0>
 __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, int64_t frame_len, bool active,
                                            int Ptrial, cf* lds, float* red, const TW& tw, const cf* w1tab, int t,
                                            cf (&Z)[Plan<N>::P], cf& zdup, float& p_est, float& m, int& dhat,
-                                           cf* yscratch, const cf* rot = nullptr, int off = 0) {
+                                           cf* yscratch, const cf* rot = nullptr, int off = 0,
+                                           cf* ukeep = nullptr, float* ekeep = nullptr) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     int* redi = reinterpret_cast<int*>(red) + 8;
@@ -40,6 +43,15 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
             if (rot) v[n0] = cmul(v[n0], rot[t + T * n0]);          // sig_with_fo = dat_time * cfo[fo]  (SynchEstAndFO.py:264)
         }
         wg_fft<N>(v, lds, tw, w1tab, t);                                                       // :152
+        if constexpr (KEEP > 0) {
+            if (t == 0) {                                   // bins 0 and N/2 both live in lane 0
+                const cf y0 = v[out_slot<N>(0, 0)], yh = v[out_slot<N>(0, PL::RL / 2)];
+                red[16] = y0.x;
+                red[17] = y0.y;
+                red[18] = yh.x;
+                red[19] = yh.y;
+            }
+        }
         int Ks_ = rx.Ks;                      // opaque per segment: keeps the 32 per-slot table offsets out of long-lived VGPRs
         asm volatile("" : "+s"(Ks_));
         const cf* zcs = rx.zc + LL * Ks_;
@@ -72,6 +84,7 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
     }
     psum = symbol_sum<T>(psum, red, t);
     p_est = sqrtf(float(rx.MM) / psum);                                                 // :157
+    if constexpr (KEEP > 0) *ekeep = psum;
 
     // del_mat[d] = sum_k e^{+j 2pi d k/N} Z[k]  == unnormalised inverse DFT of Z read at d = 0..cp
 #pragma unroll
@@ -98,6 +111,11 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
                 bi = d;
             }
         }
+    }
+    if constexpr (KEEP > 0) {
+        // lag a = t + T*q sits in register slot (j, kl) = (q % C, q / C): NC = T*C
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) ukeep[q] = cconj(v[out_slot<N>(q % PL::C, q / PL::C)]);
     }
     symbol_argmax<T>(best, bi, red, redi, t);
     m = p_est * sqrtf(best);                                                            // :164

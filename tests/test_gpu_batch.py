@@ -32,7 +32,7 @@ def _frames(N, cp, Kd, n_sym, n_frames, mod, seed, tail):
 
 @pytest.mark.parametrize("N,cp,Kd,mod,n_frames,n_sym", [
     (64, 16, 60, "QPSK", 19, 12),          # odd frame count: partially filled workgroups (8 symbols per wave)
-    (128, 32, 100, "BPSK", 7, 8),
+    (128, 32, 100, "QPSK", 7, 8),
     (256, 18, 152, "16QAM", 5, 8),
     (512, 36, 300, "64QAM", 3, 8),
     # BASELINE.json configs[4]: every cell of {1024,2048,4096}-pt x {QPSK,16-QAM,64-QAM}
