@@ -124,6 +124,14 @@ int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms);
  * reference, :143).  A frame with no sync costs one FFT pair per sample, so hosts may cap it. */
 int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials);
 
+/* Sync search of the batch path.  The reference tries the windows P = 0, 1, 2, ... one by one (:143-169); exhaustive != 0 does
+ * exactly that, one workgroup per frame.  exhaustive == 0 (default) uses the screened search where its preconditions hold
+ * (synch_dat[0] == 1, stride 1, num_synch_bins == nfft - 2): the trials between exactly evaluated anchor trials are screened
+ * with an O(cp) sliding recurrence of the lag correlations and only flagged trials are evaluated exactly -- the accepted trial,
+ * its lag and every output are those of the exhaustive search.  Returns 1 if the screened search is
+ * active for this handle afterwards, 0 if the exhaustive one is, or a negative ofdm_status. */
+int ofdm_rx_set_sync_search(ofdm_rx* h, int32_t exhaustive);
+
 /* Bytes of device workspace the batch path needs for n_frames (allocated lazily, grown on demand
  * OUTSIDE the asynchronous section: call ofdm_rx_reserve before capturing into a hipGraph). */
 int ofdm_rx_reserve(ofdm_rx* h, int64_t n_frames);

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -61,6 +62,36 @@ std::vector<cf> make_zc(int mm, int root, int parity_of) {
         z[n] = cf{float(std::cos(a)), float(std::sin(a))};
     }
     return z;
+}
+
+// G[m] = sum_i e^{+j 2pi m k_i / N} conj(zc_i), m = 0..N (G[N] = G[0]): the kernel of the screened sync search's recurrence
+// (rx_sync_scan_kernel).  Unnormalised inverse DFT of the sync symbol's conjugated grid row, iterative radix-2 in double.
+std::vector<cf> make_scan_table(int N, int Ks, const std::vector<cf>& zc) {
+    std::vector<std::complex<double>> g(size_t(N), {0.0, 0.0});
+    const int h = Ks / 2;
+    for (int i = 0; i < Ks; ++i) {
+        const int k = i < h ? N - h + i : i - h + 1;                    // binsP(Ks) (SynchAndChanEst.py:38-41)
+        g[size_t(k)] = std::conj(std::complex<double>(zc[size_t(i)].x, zc[size_t(i)].y));
+    }
+    for (int i = 1, j = 0; i < N; ++i) {                                // bit reversal
+        int bit = N >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(g[size_t(i)], g[size_t(j)]);
+    }
+    for (int len = 2; len <= N; len <<= 1) {
+        const double ang = 2.0 * M_PI / double(len);                    // e^{+j..}: inverse transform
+        for (int i = 0; i < N; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const std::complex<double> w(std::cos(ang * k), std::sin(ang * k));
+                const auto x = g[size_t(i + k)], y = g[size_t(i + k + len / 2)] * w;
+                g[size_t(i + k)] = x + y;
+                g[size_t(i + k + len / 2)] = x - y;
+            }
+    }
+    std::vector<cf> out(size_t(N) + 1);
+    for (int m = 0; m <= N; ++m) out[size_t(m)] = cf{float(g[size_t(m % N)].real()), float(g[size_t(m % N)].imag())};
+    return out;
 }
 
 template <class T>
@@ -142,6 +173,8 @@ struct ofdm_rx {
     cf* f_gain = nullptr;
     cf* f_htime = nullptr;
     int max_trials = 0;
+    int scan_block = 0;                  // > 0: the batch path's sync search is screened in blocks of this many trials
+    cf* d_scan_g = nullptr;              // [N + 1] recurrence kernel G
     int variant = 0;
     unsigned* d_stamps = nullptr;
     bool profiling = false;
@@ -252,7 +285,8 @@ int ofdm_rx_destroy(ofdm_rx* h) {
     if (!h) return OFDM_OK;
     (void)hipSetDevice(h->cfg.device);
     void* ptrs[] = {h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
-                    h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime};
+                    h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime,
+                    h->d_scan_g};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev)
@@ -307,6 +341,13 @@ int ofdm_exp_set_stamp_buffer(ofdm_rx* h, void* d_stamps) {
     return OFDM_OK;
 }
 #endif
+
+int ofdm_rx_set_sync_search(ofdm_rx* h, int32_t exhaustive) {
+    if (!h) return fail(OFDM_ERR_INVALID, "null handle");
+    h->scan_block = exhaustive ? 0 : rx_sync_scan_block(h->dev);
+    if (h->scan_block > 0 && !h->d_scan_g) h->scan_block = 0;
+    return h->scan_block > 0 ? 1 : 0;
+}
 
 int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials) {
     if (!h || max_trials < 0) return fail(OFDM_ERR_INVALID, "bad argument");
@@ -382,6 +423,19 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     }
     d.tw = h->d_tw;
     d.zc = h->d_zc;
+    h->scan_block = rx_sync_scan_block(d);
+    if (h->scan_block > 0) {
+        auto g = make_scan_table(N, Ks, zc);
+        int rc2 = dev_alloc(&h->d_scan_g, g.size());
+        if (rc2 == OFDM_OK && hipMemcpy(h->d_scan_g, g.data(), g.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess)
+            rc2 = fail(OFDM_ERR_HIP, "scan table upload failed");
+        if (rc2 != OFDM_OK) {
+            std::string keep = g_last_error;
+            ofdm_rx_destroy(h);
+            g_last_error = keep;
+            return rc2;
+        }
+    }
     *out = h;
     return OFDM_OK;
 }
@@ -445,6 +499,8 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
     sa.H_for_gain = nullptr;
     sa.gain = h->f_gain;
     sa.htime = h->f_htime;
+    sa.scan_block = h->scan_block;       // screened search where its preconditions hold (same outcome as the exhaustive one)
+    sa.scan_g = h->d_scan_g;
     hipEvent_t* pev = h->ev + 3 * (h->prof_calls % ofdm_rx::PROF_RING);
     if (h->profiling) HIP_TRY(hipEventRecord(pev[0], s));
     HIP_TRY(launch_rx_sync(d, sa, s));

@@ -57,6 +57,8 @@ struct SyncArgs {
     int gain_lag_set;        // 1: the data gains are de-rotated with gain_lag instead of the trial's lag (may be negative)
     int gain_lag;
     int force_dhat_p1;       // mode 0: lag+1 that replaces the trial's own arg-max lag (SynchEstAndFO.py:285,300); 0 = off
+    int scan_block;          // mode 0, > 0: screened search (rx_sync_scan_kernel) with blocks of this many trials
+    const cf* scan_g;        // [nfft + 1] G[m] = sum_k e^{j 2pi m k/N} conj(zc_k), G[nfft] = G[0]
 };
 
 struct DemapArgs {
@@ -135,6 +137,8 @@ hipError_t launch_tx_sync_grid(const TxDev& tx, cf* grid, hipStream_t s);
 hipError_t launch_tx_time(const TxDev& tx, const TimeArgs& a, hipStream_t s);
 hipError_t launch_tx_mux(const TxDev& tx, const MuxArgs& a, hipStream_t s);
 size_t rx_lds_bytes(int nfft);
+// block length of the screened sync search for this numerology (0: the preconditions do not hold, use the sequential search)
+int rx_sync_scan_block(const RxDev& rx);
 hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
                         hipStream_t s);
 

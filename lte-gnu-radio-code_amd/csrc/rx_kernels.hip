@@ -123,109 +123,15 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
     wg_barrier();
 }
 
-template <int N, int MINW = 3>
-__global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, SyncArgs a) {
+// ---- finalize (:171-218): LS estimate on the sync bins, equaliser gains, channel impulse response.
+// Shared by the sequential and the screened search kernels; Zs .. dhats describe the accepted trial (zeros if none).
+template <int N, class TW>
+__device__ __forceinline__ void sync_finalize(const RxDev& rx, const SyncArgs& a, int frame, bool active, bool found, int Phit,
+                                              const cf (&Zs)[Plan<N>::P], cf zdups, float pests, float ms, int dhats, cf* lds,
+                                              const TW& tw, const cf* w1tab, int t, cf* ysc) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x;
-    const int slot = tid / T;
-    const int t = tid % T;
-    cf* smem = reinterpret_cast<cf*>(smem_raw);
-    cf* lds = smem + slot * WgLds<N>::STRIDE;
-    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
-    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
-
-    // radix-16 first pass: 4 base twiddles + products on the fly (8 VGPRs instead of 30) keep the 168-register build off scratch
-    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
-    load_twiddles(tw, rx.tw, t);
-
-    const int64_t unit = int64_t(blockIdx.x) * PL::SLOTS + slot;
     const int Ks = rx.Ks, Kd = rx.Kd;
-
-    if (a.mode == 1) {
-        // ---- trial table for the stream block: unit = trial index, frame 0
-        const int n_rot = a.n_rot > 1 ? a.n_rot : 1;
-        const bool active = unit < int64_t(a.p_count) * n_rot;
-        const int cand = active ? int(unit / a.p_count) : 0;            // candidate-major: unit = cand * p_count + w
-        const int Ptrial = a.p_begin + int(unit % a.p_count);
-        const cf* rot = a.rot ? a.rot + int64_t(cand) * N : nullptr;
-        const bool valid = active && (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);  // :144
-        cf Z[P];
-        cf zdup;
-        float p_est, m;
-        int dhat;
-        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr, rot, a.off_delta);
-        if (active && t == 0) {
-            a.trial_m[unit] = valid ? m : -1.f;
-            a.trial_d[unit] = valid ? dhat : 0;
-        }
-        return;
-    }
-
-    // ---- mode 0: sequential search per frame (first accepted trial wins, :166-219), then finalize
-    const bool active = unit < a.n_frames;
-    const int frame = active ? int(unit) : 0;
-    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
-    cf* ysc = a.yscratch ? a.yscratch + int64_t(frame) * rx.MM : nullptr;
-
-    bool found = false;
-    cf Zs[P];                       // Z of the accepted trial
-    cf zdups = cf{0.f, 0.f};
-    float pests = 0.f, ms = 0.f;
-    int dhats = 0, Phit = 0;
-    if constexpr (PL::SLOTS == 1) {
-        // one frame per workgroup: every decision is workgroup-uniform, so the accepted trial's registers are used
-        // in place (no second copy of Z to keep alive across the search loop)
-        for (int it = 0;; ++it) {
-            const int Ptrial = a.p_begin + it;
-            const bool valid = active && (a.p_count <= 0 || it < a.p_count) &&
-                               (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
-            if (!valid) break;
-            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc, a.rot, a.off_delta);
-            if (a.force_dhat_p1 > 0) dhats = a.force_dhat_p1 - 1;
-            if (a.force_accept || ms > rx.gate_mm) {                                    // :166
-                found = true;
-                Phit = Ptrial;
-                break;
-            }
-        }
-        if (!found) {
-#pragma unroll
-            for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
-            zdups = cf{0.f, 0.f};
-            pests = 0.f;
-            ms = 0.f;
-            dhats = 0;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
-        for (int it = 0;; ++it) {
-            const int Ptrial = a.p_begin + it;
-            const bool valid = active && !found && (a.p_count <= 0 || it < a.p_count) &&
-                               (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
-            if (!__syncthreads_or(valid ? 1 : 0)) break;
-            cf Z[P];
-            cf zdup;
-            float p_est, m;
-            int dhat;
-            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc, a.rot, a.off_delta);
-            if (a.force_dhat_p1 > 0) dhat = a.force_dhat_p1 - 1;
-            if (valid && (a.force_accept || m > rx.gate_mm)) {                          // :166
-                found = true;
-#pragma unroll
-                for (int s = 0; s < P; ++s) Zs[s] = Z[s];
-                zdups = zdup;
-                pests = p_est;
-                ms = m;
-                dhats = dhat;
-                Phit = Ptrial;
-            }
-        }
-    }
-
-    // ---- finalize (:171-218): LS estimate on the sync bins, equaliser gains, channel impulse response
     if (active && t == 0) {
         int* o = a.tsr + int64_t(frame) * 4;
         o[0] = found ? Phit * rx.stride + rx.cp + a.off_delta : 0;                      // :173
@@ -309,6 +215,350 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, Sy
             }
         }
     }
+}
+
+template <int N, int MINW = 3>
+__global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, SyncArgs a) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
+
+    // radix-16 first pass: 4 base twiddles + products on the fly (8 VGPRs instead of 30) keep the 168-register build off scratch
+    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, rx.tw, t);
+
+    const int64_t unit = int64_t(blockIdx.x) * PL::SLOTS + slot;
+
+    if (a.mode == 1) {
+        // ---- trial table for the stream block: unit = trial index, frame 0
+        const int n_rot = a.n_rot > 1 ? a.n_rot : 1;
+        const bool active = unit < int64_t(a.p_count) * n_rot;
+        const int cand = active ? int(unit / a.p_count) : 0;            // candidate-major: unit = cand * p_count + w
+        const int Ptrial = a.p_begin + int(unit % a.p_count);
+        const cf* rot = a.rot ? a.rot + int64_t(cand) * N : nullptr;
+        const bool valid = active && (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);  // :144
+        cf Z[P];
+        cf zdup;
+        float p_est, m;
+        int dhat;
+        sync_trial<N>(rx, a.iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, nullptr, rot, a.off_delta);
+        if (active && t == 0) {
+            a.trial_m[unit] = valid ? m : -1.f;
+            a.trial_d[unit] = valid ? dhat : 0;
+        }
+        return;
+    }
+
+    // ---- mode 0: sequential search per frame (first accepted trial wins, :166-219), then finalize
+    const bool active = unit < a.n_frames;
+    const int frame = active ? int(unit) : 0;
+    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
+    cf* ysc = a.yscratch ? a.yscratch + int64_t(frame) * rx.MM : nullptr;
+
+    bool found = false;
+    cf Zs[P];                       // Z of the accepted trial
+    cf zdups = cf{0.f, 0.f};
+    float pests = 0.f, ms = 0.f;
+    int dhats = 0, Phit = 0;
+    if constexpr (PL::SLOTS == 1) {
+        // one frame per workgroup: every decision is workgroup-uniform, so the accepted trial's registers are used
+        // in place (no second copy of Z to keep alive across the search loop)
+        for (int it = 0;; ++it) {
+            const int Ptrial = a.p_begin + it;
+            const bool valid = active && (a.p_count <= 0 || it < a.p_count) &&
+                               (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+            if (!valid) break;
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats, ysc, a.rot, a.off_delta);
+            if (a.force_dhat_p1 > 0) dhats = a.force_dhat_p1 - 1;
+            if (a.force_accept || ms > rx.gate_mm) {                                    // :166
+                found = true;
+                Phit = Ptrial;
+                break;
+            }
+        }
+        if (!found) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
+            zdups = cf{0.f, 0.f};
+            pests = 0.f;
+            ms = 0.f;
+            dhats = 0;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s) Zs[s] = cf{0.f, 0.f};
+        for (int it = 0;; ++it) {
+            const int Ptrial = a.p_begin + it;
+            const bool valid = active && !found && (a.p_count <= 0 || it < a.p_count) &&
+                               (a.host_valid || int64_t(rx.S) * rx.L + int64_t(Ptrial) * rx.stride + N + rx.cp < a.frame_len);
+            if (!__syncthreads_or(valid ? 1 : 0)) break;
+            cf Z[P];
+            cf zdup;
+            float p_est, m;
+            int dhat;
+            sync_trial<N>(rx, frame_iq, a.frame_len, valid, Ptrial, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc, a.rot, a.off_delta);
+            if (a.force_dhat_p1 > 0) dhat = a.force_dhat_p1 - 1;
+            if (valid && (a.force_accept || m > rx.gate_mm)) {                          // :166
+                found = true;
+#pragma unroll
+                for (int s = 0; s < P; ++s) Zs[s] = Z[s];
+                zdups = zdup;
+                pests = p_est;
+                ms = m;
+                dhats = dhat;
+                Phit = Ptrial;
+            }
+        }
+    }
+
+    sync_finalize<N>(rx, a, frame, active, found, Phit, Zs, zdups, pests, ms, dhats, lds, tw, w1tab, t, ysc);
+}
+
+// ------------------------------------------------------------------------------------------ screened sync search
+// The reference tries the windows P = 0, 1, 2, ... one sample apart and, for each, forms the cp+1 lag correlations
+// c_P[d] = sum_k e^{j 2pi d k/N} Y_P[k] conj(zc_k) from a fresh FFT (SynchAndChanEst.py:143-164).  Consecutive windows
+// share N-1 samples: with D_P = x[w+N] - x[w] (w = first sample of window P),
+//     Y_{P+1}[k] = (Y_P[k] + D_P) e^{j 2pi k/N}      =>      c_{P+1}[d] = c_P[d+1] + D_P * G[d+1],
+//     G[m] = sum_k e^{j 2pi m k/N} conj(zc_k)   (a table, built once per handle)
+// and, for num_synch_bins = N-2 (every bin but DC and Nyquist, the reference's convention), the in-band energy that
+// normalises the correlation (:157) follows from three sliding sums:  E_P = N sum|x|^2 - |sum x|^2 - |sum (-1)^n x|^2.
+// In "alignment" coordinates a = d + (P - P0) every correlation value is a running sum u[a] += D * G[a - j + 1], one
+// complex multiply-add per step j and alignment: O(B + cp) per trial instead of two N-point FFTs.
+//
+// The recurrence runs in fp32, so it only SCREENS: a block of B trials starts from an exactly evaluated anchor trial
+// (the same sync_trial as everywhere else); a trial whose screened peak exceeds (1 - 1e-3) * gate * MM -- or whose window
+// energy is too small for the sliding sums to be trusted -- is re-evaluated exactly, in order, and only the exact value
+// decides (:166).  Trials the screen rejects lie at least 1e-3 * gate * MM below the gate, two orders of magnitude more
+// than the recurrence can drift over one block (<= 128 steps of ~6e-8 relative rounding), so the accepted trial and its
+// lag are those of the exhaustive search.  Frames whose sync sits at trial 0 never enter the recurrence.
+// Preconditions checked by the host: S == 1, stride == 1, Ks == N - 2, no rotator, B + cp <= SCAN_QM * T.
+template <int N>
+struct ScanGeom {
+    static constexpr int T = Plan<N>::T;
+    static constexpr int QM = (T >= 256) ? 2 : (T >= 128) ? 3 : (T >= 64) ? 4 : (T >= 32) ? 6 : (Plan<N>::P < 12 ? Plan<N>::P : 12);
+    static constexpr int BMAX = 128;
+    static constexpr int RMAX = (BMAX + T - 1) / T;                   // edge samples per lane
+    // extra LDS per slot (cf units): xo[BMAX] xn[BMAX] G[QM*T + 1] thr[BMAX floats]
+    static constexpr int EXTRA = 2 * BMAX + (QM * T + 2) + BMAX / 2;
+    static constexpr size_t BYTES = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * EXTRA * sizeof(cf);
+};
+
+template <int N, int MINW = 2>
+__global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev rx, SyncArgs a) {
+    using PL = Plan<N>;
+    using SG = ScanGeom<N>;
+    constexpr int T = PL::T, P = PL::P, QM = SG::QM, SLOTS = PL::SLOTS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
+    int* redi = reinterpret_cast<int*>(red);
+    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
+    cf* extra = smem + WgLds<N>::STRIDE * SLOTS + WgLds<N>::W1_ELEMS + slot * SG::EXTRA;
+    cf* xo = extra;
+    cf* xn = extra + SG::BMAX;
+    cf* Gl = extra + 2 * SG::BMAX;
+    float* thr = reinterpret_cast<float*>(extra + 2 * SG::BMAX + QM * T + 2);
+
+    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, rx.tw, t);
+
+    const int64_t unit = int64_t(blockIdx.x) * SLOTS + slot;
+    const bool active = unit < a.n_frames;
+    const int frame = active ? int(unit) : 0;
+    const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
+    // (a run-time pointer on purpose: with a literal nullptr hipcc's schedule of the trial needs ~3000 spills at 168 VGPRs)
+    cf* ysc = a.yscratch ? a.yscratch + int64_t(frame) * rx.MM : nullptr;
+    const int B = a.scan_block, cp = rx.cp;
+    // number of valid trials of this frame: P valid iff S*L + P + N + cp < frame_len (:144), P < p_count
+    int64_t nvalid64 = a.frame_len - (int64_t(rx.S) * rx.L + N + cp);
+    if (nvalid64 < 0) nvalid64 = 0;
+    if (a.p_count > 0 && nvalid64 > a.p_count) nvalid64 = a.p_count;
+    const int nvalid = active ? int(nvalid64 < (1 << 30) ? nvalid64 : (1 << 30)) : 0;
+
+    // the table G[1 .. B + cp] -> LDS once (index 0 unused)
+    for (int i = t; i <= QM * T; i += T) Gl[i] = a.scan_g[i];
+
+    // Every iteration evaluates ONE trial exactly (the anchor at P0) and then screens the trials after it; the first flagged
+    // trial becomes the next anchor, so "verification" and "anchor" are the same code.  The accepted trial is always the most
+    // recent anchor: with one frame per workgroup its registers are used in place.
+    bool found = false;
+    cf Zs[P];
+    cf zdups = cf{0.f, 0.f};
+    float pests = 0.f, ms = 0.f;
+    int dhats = 0, Phit = 0;
+    if constexpr (SLOTS > 1) {
+#pragma unroll
+        for (int s_ = 0; s_ < P; ++s_) Zs[s_] = cf{0.f, 0.f};
+    }
+    const float gate_s = rx.gate_mm * (1.f - 1e-3f);
+    const float thr_k = gate_s * gate_s / float(rx.MM);                // |u|^2 > thr_k * E  <=>  p_est |u| > gate_s
+
+    int P0 = 0;
+    for (;;) {
+        const bool blk_on = !found && P0 < nvalid;
+        if (!__syncthreads_or(blk_on ? 1 : 0)) break;
+        // ---- (1) anchor: exact trial at P0
+        cf u[QM];
+        float e0;
+        if constexpr (SLOTS == 1) {
+            sync_trial<N, decltype(tw), QM>(rx, frame_iq, a.frame_len, blk_on, P0, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats,
+                                            ysc, nullptr, 0, u, &e0);
+            if (ms > rx.gate_mm) {                                                      // :166 (blk_on is workgroup-uniform here)
+                found = true;
+                Phit = P0;
+                break;
+            }
+        } else {
+            cf Z[P];
+            cf zdup;
+            float p_est, m;
+            int dhat;
+            sync_trial<N, decltype(tw), QM>(rx, frame_iq, a.frame_len, blk_on, P0, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc,
+                                            nullptr, 0, u, &e0);
+            if (blk_on && m > rx.gate_mm) {                                             // :166
+                found = true;
+                Phit = P0;
+#pragma unroll
+                for (int s_ = 0; s_ < P; ++s_) Zs[s_] = Z[s_];
+                zdups = zdup;
+                pests = p_est;
+                ms = m;
+                dhats = dhat;
+            }
+        }
+        const cf y0 = cf{red[16], red[17]}, yh = cf{red[18], red[19]};
+        // ---- (2) screen the trials P0+1 .. P0+nb-1 with the recurrence
+        const int nb = (blk_on && !found) ? min(B, nvalid - P0) : 0;      // trials of this block (incl. the anchor)
+        int cand = 0x7fffffff;
+        if (__syncthreads_or(nb > 1 ? 1 : 0)) {
+            // window edges: xo[i] = x[w0 + i], xn[i] = x[w0 + N + i], w0 = P0 + cp;  i < nb - 1
+            const int64_t w0 = int64_t(P0) + cp;
+            float dw = 0.f, wadd = 0.f;
+            cf da = cf{0.f, 0.f}, db = cf{0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < SG::RMAX; ++r) {
+                const int i = t * SG::RMAX + r;                          // contiguous chunk per lane
+                if (i < nb - 1) {
+                    const cf o = frame_iq[w0 + i], n_ = frame_iq[w0 + N + i];
+                    xo[i] = o;
+                    xn[i] = n_;
+                    const float sgn = (i & 1) ? 1.f : -1.f;             // (-1)^(i+1)
+                    dw += cnorm2(n_) - cnorm2(o);
+                    wadd += cnorm2(n_);
+                    da = da + (n_ - o);
+                    db = db + cscale(o - n_, sgn);
+                }
+            }
+            // inclusive scan of the per-lane totals over the T lanes of the slot (T <= 64: inside one wave; else via LDS)
+            float sw = dw, swa = wadd;
+            cf sa = da, sb = db;
+            constexpr int W = T < 64 ? T : 64;
+#pragma unroll
+            for (int dlt = 1; dlt < W; dlt <<= 1) {
+                const float o1 = __shfl_up(sw, dlt, W), o2 = __shfl_up(swa, dlt, W);
+                const float o3 = __shfl_up(sa.x, dlt, W), o4 = __shfl_up(sa.y, dlt, W);
+                const float o5 = __shfl_up(sb.x, dlt, W), o6 = __shfl_up(sb.y, dlt, W);
+                if ((t & (W - 1)) >= dlt) {
+                    sw += o1;
+                    swa += o2;
+                    sa = sa + cf{o3, o4};
+                    sb = sb + cf{o5, o6};
+                }
+            }
+            float tot_add;
+            if constexpr (T > 64) {
+                // BMAX <= 128 <= T and one element per lane: only the first two waves carry elements
+                if ((t & 63) == 63 && t < 128) {
+                    float* r6 = red + (t >> 6) * 6;
+                    r6[0] = sw;
+                    r6[1] = swa;
+                    r6[2] = sa.x;
+                    r6[3] = sa.y;
+                    r6[4] = sb.x;
+                    r6[5] = sb.y;
+                }
+                wg_barrier();
+                if (t >= 64) {
+                    sw += red[0];
+                    sa = sa + cf{red[2], red[3]};
+                    sb = sb + cf{red[4], red[5]};
+                }
+                tot_add = red[1] + red[7];
+            } else {
+                tot_add = __shfl(swa, W - 1, W);
+            }
+            // exclusive prefix of this lane's chunk
+            float pw = sw - dw;
+            cf pa = sa - da, pb = sb - db;
+            // anchor: E_0 = e0 (in band), N W_0 = e0 + |Y[0]|^2 + |Y[N/2]|^2, sum x = Y[0], sum (-1)^n x = Y[N/2]
+            const float nw0 = e0 + cnorm2(y0) + cnorm2(yh);
+            const float wbound = nw0 + float(N) * tot_add;               // >= N W_j for every j of the block
+#pragma unroll
+            for (int r = 0; r < SG::RMAX; ++r) {
+                const int i = t * SG::RMAX + r;
+                if (i < nb - 1) {
+                    const cf o = xo[i], n_ = xn[i];
+                    const float sgn = (i & 1) ? 1.f : -1.f;
+                    pw += cnorm2(n_) - cnorm2(o);
+                    pa = pa + (n_ - o);
+                    pb = pb + cscale(o - n_, sgn);
+                    // state AFTER step i, i.e. of trial j = i + 1
+                    const float nwj = nw0 + float(N) * pw;
+                    const float ej = nwj - cnorm2(y0 + pa) - cnorm2(yh + pb);
+                    // too little energy left for the sliding sums to be trusted -> force an exact evaluation
+                    const bool weak = !(nwj > 1e-4f * wbound) || !(ej > 1e-3f * nwj);
+                    thr[i + 1] = weak ? -1.f : thr_k * ej;
+                }
+            }
+            wg_barrier();
+            // ---- recurrence over the steps j = 1 .. nb-1.  No barrier inside: lanes leave the loop on their own (first flagged
+            // trial, or the end of their frame's block)
+            for (int j = 1; j < nb; ++j) {
+                const cf d = xn[j - 1] - xo[j - 1];
+                const float th = thr[j];
+                bool h = false;
+#pragma unroll
+                for (int q = 0; q < QM; ++q) {
+                    const int idx = t + T * q - j + 1;                   // G index; the lag of alignment t + T*q at trial j is idx - 1
+                    if (idx >= 1 && idx <= QM * T) {
+                        u[q] = u[q] + cmul(d, Gl[idx]);
+                        h |= (idx - 1 <= cp) && (cnorm2(u[q]) > th);
+                    }
+                }
+                if (h) {
+                    cand = j;
+                    break;
+                }
+            }
+            // first flagged trial of the slot
+#pragma unroll
+            for (int mk = W >> 1; mk >= 1; mk >>= 1) cand = min(cand, __shfl_xor(cand, mk, W));
+            if constexpr (T > 64) {
+                wg_barrier();                                            // red[] above has been read by everyone
+                if ((t & 63) == 0) redi[t >> 6] = cand;
+                wg_barrier();
+                int c2 = redi[0];
+#pragma unroll
+                for (int w = 1; w < T / 64; ++w) c2 = min(c2, redi[w]);
+                cand = c2;
+                wg_barrier();
+            }
+        }
+        // the first flagged trial is the next anchor (evaluated exactly there); an unflagged block is skipped whole
+        if (nb > 0) P0 += (cand < nb) ? cand : nb;
+    }
+    sync_finalize<N>(rx, a, frame, active, found, Phit, Zs, zdups, pests, ms, dhats, lds, tw, w1tab, t, ysc);
 }
 
 // ------------------------------------------------------------------------------------------ standalone de-mapper
@@ -505,10 +755,28 @@ __global__ void despread_kernel(const cf* in, int in_row_stride, const cf* code,
 
 // ------------------------------------------------------------------------------------------ launchers
 template <int N>
+static int scan_block_n(const RxDev& rx) {
+    using SG = ScanGeom<N>;
+    if (rx.S != 1 || rx.stride != 1 || rx.Ks != N - 2) return 0;
+    int B = SG::QM * SG::T - rx.cp;
+    if (B > SG::BMAX) B = SG::BMAX;
+    return B >= 16 ? B : 0;
+}
+
+template <int N>
 static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
     const int64_t units = (a.mode == 1) ? int64_t(a.p_count) * (a.n_rot > 1 ? a.n_rot : 1) : a.n_frames;
     const unsigned grid = unsigned((units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
     if (grid == 0) return hipSuccess;
+    if (a.mode == 0 && a.scan_block > 0) {
+        if (a.scan_block != scan_block_n<N>(rx) || !a.scan_g || a.rot || a.force_accept || a.host_valid || a.off_delta || a.force_dhat_p1 ||
+            a.p_begin != 0)
+            return hipErrorInvalidValue;
+        // register budget: 168 VGPRs (3 waves per SIMD) costs ~23 spills for one frame per workgroup (N >= 1024); the packed small
+        // sizes keep a second copy of Z and get 256
+        hipLaunchKernelGGL((rx_sync_scan_kernel<N, (N >= 1024 ? 3 : 2)>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
+        return hipGetLastError();
+    }
     // 3 waves per SIMD (168 VGPRs, a few spills off the trial path): 0.14 ms instead of 0.21 ms per 4369-frame launch; the
     // unconstrained build takes 192 VGPRs + 256 AGPRs (1 wave per SIMD), a 128-register build spills into the trial (0.20 ms)
     hipLaunchKernelGGL((rx_sync_kernel<N, 3>), dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, a);
@@ -536,6 +804,18 @@ hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
 #define CALL(n) launch_sync_n<n>(rx, a, s)
     OFDM_DISPATCH_N(rx.nfft, CALL)
 #undef CALL
+}
+int rx_sync_scan_block(const RxDev& rx) {
+    switch (rx.nfft) {
+        case 64: return scan_block_n<64>(rx);
+        case 128: return scan_block_n<128>(rx);
+        case 256: return scan_block_n<256>(rx);
+        case 512: return scan_block_n<512>(rx);
+        case 1024: return scan_block_n<1024>(rx);
+        case 2048: return scan_block_n<2048>(rx);
+        case 4096: return scan_block_n<4096>(rx);
+    }
+    return 0;
 }
 size_t rx_lds_bytes(int nfft) {
 #define CALL(n) WgLds<n>::BYTES

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "ofdm_rx_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "ofdm_rx_get_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ofdm_rx_set_max_trials": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ofdm_rx_set_sync_search": (C.c_int, [C.c_void_p, C.c_int32]),
     "ofdm_demap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofdm_fo_create": (C.c_int, [C.POINTER(FoCfg), C.POINTER(C.c_void_p)]),
     "ofdm_fo_destroy": (C.c_int, [C.c_void_p]),

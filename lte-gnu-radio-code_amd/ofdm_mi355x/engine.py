@@ -135,6 +135,10 @@ class RxEngine:
         check(self.lib.ofdm_rx_get_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
+    def set_sync_search(self, exhaustive: bool) -> bool:
+        """True if the screened sync search is active afterwards (False: the exhaustive, trial-by-trial one)."""
+        return bool(check(self.lib.ofdm_rx_set_sync_search(self._h, int(bool(exhaustive)))))
+
     def set_max_trials(self, n: int):
         check(self.lib.ofdm_rx_set_max_trials(self._h, int(n)))
 

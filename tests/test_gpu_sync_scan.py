@@ -1,0 +1,125 @@
+"""GPU parity of the batch path's sync search with frames that do NOT start at sample 0 (run with -m gpu).
+
+Every frame is preceded by its own random lead of 0..L-1 noise samples, so the search of every frame ends at a different
+trial, deep inside the frame or -- with a trial cap -- not at all.  `time_synch_ref` must equal the oracle's (position and lag
+exactly, int(peak) within 1), the equalised symbols must match at 1e-5, and the screened search (anchor trials evaluated
+exactly, the trials between them screened by the sliding recurrence) must return byte for byte what the exhaustive
+trial-by-trial search returns."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import ofdm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def om():
+    import ofdm_mi355x
+    ofdm_mi355x.load()
+    return ofdm_mi355x
+
+
+def _frames_with_leads(N, cp, Kd, n_sym, leads, sigma, seed, lead_kind="noise", taps=orc.REF_TAPS):
+    rng = np.random.default_rng(seed)
+    L = N + cp
+    fl = n_sym * L + 7
+    nb = (n_sym // 4) * 3 * Kd * 2
+    iq = np.zeros((len(leads), fl), np.complex64)
+    bits = rng.integers(0, 2, (len(leads), nb)).astype(np.uint8)
+    for f, ld in enumerate(leads):
+        tx = orc.channel_apply(orc.tx_modulate(bits[f], N, cp, N - 2, Kd, n_sym), taps, N)
+        pre = np.zeros(ld, complex) if lead_kind == "zeros" else 0.3 * (rng.standard_normal(ld) + 1j * rng.standard_normal(ld))
+        x = np.concatenate([pre, tx])[:fl]
+        x = np.concatenate([x, np.zeros(fl - len(x))])
+        iq[f] = (x + sigma * (rng.standard_normal(fl) + 1j * rng.standard_normal(fl))).astype(np.complex64)
+    return bits, iq
+
+
+def _run(om, rx, iq, Kd, exhaustive, max_trials=0):
+    n_frames, fl = iq.shape
+    assert rx.set_sync_search(exhaustive) == (not exhaustive)
+    rx.set_max_trials(max_trials)
+    nds = rx.data_symbols_per_frame(fl)
+    d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+    d_eq = om.DeviceBuffer(max(8, n_frames * nds * Kd * 8))
+    d_b = om.DeviceBuffer(max(8, n_frames * nds * Kd * 2))
+    d_tsr = om.DeviceBuffer(n_frames * 16)
+    rx.demod_frames(d_iq, n_frames, fl, fl, d_eq, d_b, om.BITS_UNPACKED, d_tsr)
+    eq = d_eq.download(np.complex64, n_frames * nds * Kd).reshape(n_frames, nds, Kd)
+    b = d_b.download(np.uint8, n_frames * nds * Kd * 2).reshape(n_frames, -1)
+    tsr = d_tsr.download(np.int32, n_frames * 4).reshape(n_frames, 4)
+    H = np.stack([rx.frame_state(f)["chan_freq"] for f in range(n_frames)])
+    return eq, b, tsr, H
+
+
+@pytest.mark.parametrize("N,cp,Kd,n_sym,n_frames,sigma,max_lead", [
+    (64, 16, 60, 12, 40, 0.05, None), (128, 32, 100, 8, 16, 0.05, None), (256, 64, 180, 8, 12, 0.1, None),
+    (512, 36, 300, 8, 8, 0.05, None), (1024, 72, 600, 8, 8, 0.05, None), (2048, 144, 1200, 8, 6, 0.05, None),
+    (4096, 288, 2400, 4, 3, 0.02, 1500),
+])
+def test_random_leads_match_the_oracle(om, N, cp, Kd, n_sym, n_frames, sigma, max_lead):
+    L = N + cp
+    rng = np.random.default_rng(N)
+    leads = rng.integers(0, max_lead or L, n_frames)
+    leads[0] = 0                                               # one aligned frame among them
+    leads[1] = (max_lead or L) - 1
+    bits, iq = _frames_with_leads(N, cp, Kd, n_sym, leads, sigma, seed=N + 1)
+    fl = iq.shape[1]
+    rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 30, 0.7)
+    eq_s, b_s, tsr_s, H_s = _run(om, rx, iq, Kd, exhaustive=False)
+    eq_x, b_x, tsr_x, H_x = _run(om, rx, iq, Kd, exhaustive=True)
+    assert np.array_equal(tsr_s, tsr_x) and np.array_equal(eq_s.view(np.uint32), eq_x.view(np.uint32))
+    assert np.array_equal(b_s, b_x) and np.array_equal(H_s.view(np.uint32), H_x.view(np.uint32))
+    rows = [r for r in range(n_sym) if r % 4 != 3]
+    hits = set()
+    for f in range(n_frames):
+        o = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 30, 0.7, force_fp64=True)
+        o.work(iq[f], np.zeros(fl, np.complex64))
+        assert tsr_s[f, 3] == 1 and tsr_s[f, 0] == o.time_synch_ref[0] and tsr_s[f, 1] == o.time_synch_ref[1], (f, leads[f], tsr_s[f], o.time_synch_ref)
+        assert abs(tsr_s[f, 2] - o.time_synch_ref[2]) <= 1
+        hits.add(int(tsr_s[f, 0]))
+        nd = eq_s.shape[1]
+        ref = o.est_data_freq[rows][:nd]
+        ok = np.isfinite(ref).all(axis=1) & (np.abs(ref).max(axis=1) > 0)          # patterns the lead pushed past the frame end
+        full = [r for r in range(nd) if ok[r] and leads[f] + cp + (r // 3 * 4 + 1 + r % 3) * L + N <= fl]
+        assert_close(eq_s[f][full], ref[full], "frame %d (lead %d)" % (f, leads[f]))
+    assert len(hits) > min(4, n_frames - 2)                    # the search really ended at different trials
+
+
+def test_zero_leads_noise_only_frames_and_trial_cap(om):
+    """Leads of exact zeros (the window energy is 0: the screen must hand those trials to the exact evaluation), a frame of pure
+    noise (no sync anywhere), and a trial cap below some frames' sync position: identical to the exhaustive search and to the
+    oracle's verdict."""
+    N, cp, Kd, n_sym = 256, 64, 180, 8
+    L = N + cp
+    leads = np.array([0, 5, 100, 250, 319, 30, 310, 200])
+    bits, iq = _frames_with_leads(N, cp, Kd, n_sym, leads, 0.0, seed=9, lead_kind="zeros")
+    rng = np.random.default_rng(3)
+    iq[5] = (0.2 * (rng.standard_normal(iq.shape[1]) + 1j * rng.standard_normal(iq.shape[1]))).astype(np.complex64)
+    fl = iq.shape[1]
+    rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+    for cap in (0, 150):
+        s = _run(om, rx, iq, Kd, exhaustive=False, max_trials=cap)
+        x = _run(om, rx, iq, Kd, exhaustive=True, max_trials=cap)
+        for a, b in zip(s, x):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+        tsr = s[2]
+        assert tsr[5, 3] == 0 and not tsr[5].any() and not s[0][5].any()
+        for f in (0, 1, 2, 3, 4, 6, 7):
+            o = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 100, 0.7, force_fp64=True)
+            o.work(iq[f], np.zeros(fl, np.complex64))
+            p_hit = int(o.time_synch_ref[0]) - cp
+            if cap and p_hit >= cap:
+                assert tsr[f, 3] == 0, (f, cap, p_hit)
+            else:
+                assert tsr[f, 3] == 1 and tsr[f, 0] == o.time_synch_ref[0] and tsr[f, 1] == o.time_synch_ref[1]
+
+
+def test_screen_is_off_where_its_preconditions_fail(om):
+    assert om.RxEngine(8, 64, 16, 62, (1, 3), 60, 100).set_sync_search(False) is True
+    assert om.RxEngine(8, 64, 16, 60, (1, 3), 60, 100).set_sync_search(False) is False          # Ks != N - 2
+    assert om.RxEngine(10, 64, 16, 62, (2, 3), 60, 100).set_sync_search(False) is False         # two sync symbols per pattern
+    assert om.RxEngine(8, 64, 16, 62, (1, 3), 60, 100, compat=om.COMPAT_RXOFDM).set_sync_search(False) is False   # stride cp-1
+    assert om.RxEngine(8, 64, 60, 62, (1, 3), 60, 100).set_sync_search(False) is False          # cp too long for one block
