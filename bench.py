@@ -311,6 +311,8 @@ def main(argv=None):
     ap.add_argument("--mod", default=None, choices=sorted(BPS), help="override the config's constellation (numerology sweep)")
     ap.add_argument("--lead", default="aligned", choices=["aligned", "random"],
                     help="random: every frame starts after its own 0..L-1 sample lead (sync found at a different trial per frame)")
+    ap.add_argument("--sync-search", default="screened", choices=["screened", "exhaustive"],
+                    help="exhaustive: the reference's trial-by-trial sync search (A/B against the screened search; same outputs)")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the N-rank control flow on CPU/gloo (tests); no GPU work")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -373,6 +375,7 @@ def main(argv=None):
     # aligned frames: the sync sits at trial 0 by construction, never scan more than one symbol period; random leads: the
     # lead is < L, two symbol periods cover it
     rxe.set_max_trials(L if args.lead == "aligned" else 2 * L)
+    sync_mode = "screened" if rxe.set_sync_search(args.sync_search == "exhaustive") else "exhaustive"
     rxe.set_profiling(True)
     nds = rxe.data_symbols_per_frame(fl)
     bytes_per_frame_bits = nds * Kd * bps // 8
@@ -536,7 +539,7 @@ def main(argv=None):
                        # stream-equivalent: every input sample counted at 8 B, although CP samples and 59 of 60 sync symbols per
                        # frame are never fetched (BASELINE.md's "HBM-read roofline" definition); roofline.physical_read_GBs is fetched bytes
                        "stream_equivalent_read_fraction_of_8TBs": round(value * 1e6 * 8 / world / 8e12, 4),
-                       "bit_error_rate_frame0": ber, "all_gather": gather_info},
+                       "bit_error_rate_frame0": ber, "sync_search": sync_mode, "all_gather": gather_info},
             "roofline": roof, "cpu_baseline": cpu,
         }
     if dist is not None:

@@ -343,10 +343,12 @@ template <int N>
 struct ScanGeom {
     static constexpr int T = Plan<N>::T;
     static constexpr int QM = (T >= 256) ? 2 : (T >= 128) ? 3 : (T >= 64) ? 4 : (T >= 32) ? 6 : (Plan<N>::P < 12 ? Plan<N>::P : 12);
-    static constexpr int BMAX = 128;
-    static constexpr int RMAX = (BMAX + T - 1) / T;                   // edge samples per lane
-    // extra LDS per slot (cf units): xo[BMAX] xn[BMAX] G[QM*T + 1] thr[BMAX floats]
-    static constexpr int EXTRA = 2 * BMAX + (QM * T + 2) + BMAX / 2;
+    static constexpr int BMAX = (QM * T < 256) ? QM * T : 256;        // longest block (trials per anchor)
+    static constexpr int RMAX = (BMAX + T - 1) / T;                   // window-edge samples per lane
+    static constexpr int UNR = QM >= 8 ? 2 : 4;                       // recurrence steps per loop iteration (register budget)
+    // extra LDS per slot (cf units): dl[BMAX + UNR] | xn[BMAX] | G[QM*T + 2] | thr[BMAX + UNR floats]
+    static constexpr int DL_OFF = 0, XN_OFF = BMAX + UNR, G_OFF = XN_OFF + BMAX, THR_OFF = G_OFF + QM * T + 2;
+    static constexpr int EXTRA = THR_OFF + (BMAX + UNR + 1) / 2;
     static constexpr size_t BYTES = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * EXTRA * sizeof(cf);
 };
 
@@ -365,10 +367,10 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     int* redi = reinterpret_cast<int*>(red);
     const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
     cf* extra = smem + WgLds<N>::STRIDE * SLOTS + WgLds<N>::W1_ELEMS + slot * SG::EXTRA;
-    cf* xo = extra;
-    cf* xn = extra + SG::BMAX;
-    cf* Gl = extra + 2 * SG::BMAX;
-    float* thr = reinterpret_cast<float*>(extra + 2 * SG::BMAX + QM * T + 2);
+    cf* xo = extra + SG::DL_OFF;          // window-edge samples leaving; overwritten by dl[i] = xn[i] - xo[i]
+    cf* xn = extra + SG::XN_OFF;          // window-edge samples entering
+    cf* Gl = extra + SG::G_OFF;
+    float* thr = reinterpret_cast<float*>(extra + SG::THR_OFF);
 
     std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
     load_twiddles(tw, rx.tw, t);
@@ -386,8 +388,8 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     if (a.p_count > 0 && nvalid64 > a.p_count) nvalid64 = a.p_count;
     const int nvalid = active ? int(nvalid64 < (1 << 30) ? nvalid64 : (1 << 30)) : 0;
 
-    // the table G[1 .. B + cp] -> LDS once (index 0 unused)
-    for (int i = t; i <= QM * T; i += T) Gl[i] = a.scan_g[i];
+    // the table G[1 .. B + cp] -> LDS once; entry 0 is a ZERO so that out-of-range alignments add nothing, branch-free
+    for (int i = t; i <= QM * T; i += T) Gl[i] = i ? a.scan_g[i] : cf{0.f, 0.f};
 
     // Every iteration evaluates ONE trial exactly (the anchor at P0) and then screens the trials after it; the first flagged
     // trial becomes the next anchor, so "verification" and "anchor" are the same code.  The accepted trial is always the most
@@ -478,9 +480,9 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             }
             float tot_add;
             if constexpr (T > 64) {
-                // BMAX <= 128 <= T and one element per lane: only the first two waves carry elements
-                if ((t & 63) == 63 && t < 128) {
-                    float* r6 = red + (t >> 6) * 6;
+                constexpr int NW = T / 64;
+                if ((t & 63) == 63) {
+                    float* r6 = red + (t >> 6) * 6;                      // NW <= 4 waves x 6 floats = the 24-dword scratch
                     r6[0] = sw;
                     r6[1] = swa;
                     r6[2] = sa.x;
@@ -489,12 +491,17 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     r6[5] = sb.y;
                 }
                 wg_barrier();
-                if (t >= 64) {
-                    sw += red[0];
-                    sa = sa + cf{red[2], red[3]};
-                    sb = sb + cf{red[4], red[5]};
+                tot_add = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const float* r6 = red + w * 6;
+                    tot_add += r6[1];
+                    if (w < (t >> 6)) {
+                        sw += r6[0];
+                        sa = sa + cf{r6[2], r6[3]};
+                        sb = sb + cf{r6[4], r6[5]};
+                    }
                 }
-                tot_add = red[1] + red[7];
             } else {
                 tot_add = __shfl(swa, W - 1, W);
             }
@@ -519,26 +526,48 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     // too little energy left for the sliding sums to be trusted -> force an exact evaluation
                     const bool weak = !(nwj > 1e-4f * wbound) || !(ej > 1e-3f * nwj);
                     thr[i + 1] = weak ? -1.f : thr_k * ej;
+                    xo[i] = n_ - o;                                      // dl[i] (this lane's own entry)
                 }
             }
+            // padding read by the unrolled loop past the block's last step: adds nothing, never flags
+            for (int idx = t; idx < SG::BMAX + SG::UNR; idx += T) {
+                if (idx >= nb - 1) xo[idx] = cf{0.f, 0.f};
+                if (idx >= nb) thr[idx] = 3.0e38f;
+            }
             wg_barrier();
-            // ---- recurrence over the steps j = 1 .. nb-1.  No barrier inside: lanes leave the loop on their own (first flagged
-            // trial, or the end of their frame's block)
-            for (int j = 1; j < nb; ++j) {
-                const cf d = xn[j - 1] - xo[j - 1];
-                const float th = thr[j];
-                bool h = false;
+            // ---- recurrence over the steps j = 1 .. nb-1, UNR steps per iteration with all their LDS reads issued up front.
+            // No barrier inside: lanes leave the loop on their own (first flagged trial, or the end of their frame's block).
+            {
+                const cf* dl = xo;
+                for (int j = 1; j < nb; j += SG::UNR) {
+                    cf dd[SG::UNR], gg[SG::UNR][QM];
+                    float th[SG::UNR];
 #pragma unroll
-                for (int q = 0; q < QM; ++q) {
-                    const int idx = t + T * q - j + 1;                   // G index; the lag of alignment t + T*q at trial j is idx - 1
-                    if (idx >= 1 && idx <= QM * T) {
-                        u[q] = u[q] + cmul(d, Gl[idx]);
-                        h |= (idx - 1 <= cp) && (cnorm2(u[q]) > th);
+                    for (int s_ = 0; s_ < SG::UNR; ++s_) {
+                        dd[s_] = dl[j + s_ - 1];
+                        th[s_] = thr[j + s_];
+#pragma unroll
+                        for (int q = 0; q < QM; ++q) {
+                            const int idx = t + T * q - (j + s_) + 1;    // G index; the lag of alignment t + T*q at that trial is idx - 1
+                            gg[s_][q] = Gl[unsigned(idx - 1) < unsigned(QM * T) ? idx : 0];
+                        }
                     }
-                }
-                if (h) {
-                    cand = j;
-                    break;
+                    int first = SG::UNR;
+#pragma unroll
+                    for (int s_ = 0; s_ < SG::UNR; ++s_) {
+                        bool h = false;
+#pragma unroll
+                        for (int q = 0; q < QM; ++q) {
+                            const int lag = t + T * q - (j + s_);
+                            u[q] = u[q] + cmul(dd[s_], gg[s_][q]);
+                            h |= (unsigned(lag) <= unsigned(cp)) && (cnorm2(u[q]) > th[s_]);
+                        }
+                        if (h && first == SG::UNR) first = s_;
+                    }
+                    if (first < SG::UNR) {
+                        cand = j + first;
+                        break;
+                    }
                 }
             }
             // first flagged trial of the slot
