@@ -99,8 +99,8 @@ def build_inputs(torch, om, cfg, n_frames, device, seed, lead="aligned"):
     # reference noise law (MultiAntennaSystem.py:244, 'Digital'): var = L/(Kd*bps) * sig_pow * 10^(-SNR/10), sig_pow = 1
     noise_var = (L / (Kd * bps)) * 10 ** (-cfg["snr_db"] / 10)
     leads = None
-    if lead == "random":
-        leads = np.random.default_rng(seed + 7).integers(0, L, n_frames)
+    if lead != "aligned":
+        leads = np.random.default_rng(seed + 7).integers(0, L, n_frames) if lead == "random" else np.full(n_frames, int(lead))
         d_rx.normal_(0.0, float(np.sqrt(noise_var / 2)), generator=g)         # the lead samples are noise only
     stream = torch.cuda.current_stream().cuda_stream
     step = 256
@@ -309,8 +309,9 @@ def main(argv=None):
     ap.add_argument("--no-probes", action="store_true", help="skip the copy / access-pattern / power context probes")
     ap.add_argument("--chunks", type=int, default=4, help="sub-batches per step for all-gather overlap (N>1)")
     ap.add_argument("--mod", default=None, choices=sorted(BPS), help="override the config's constellation (numerology sweep)")
-    ap.add_argument("--lead", default="aligned", choices=["aligned", "random"],
-                    help="random: every frame starts after its own 0..L-1 sample lead (sync found at a different trial per frame)")
+    ap.add_argument("--lead", default="aligned",
+                    help="aligned | random (every frame starts after its own 0..L-1 sample lead: the sync search of every frame ends "
+                         "at a different trial) | <int> (the same lead for every frame; kernel studies)")
     ap.add_argument("--sync-search", default="screened", choices=["screened", "exhaustive"],
                     help="exhaustive: the reference's trial-by-trial sync search (A/B against the screened search; same outputs)")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the N-rank control flow on CPU/gloo (tests); no GPU work")
@@ -362,6 +363,8 @@ def main(argv=None):
         cfg["mod"] = args.mod
     if args.lead == "random":
         cfg["name"] += ", per-frame random lead 0..L-1"
+    elif args.lead != "aligned":
+        cfg["name"] += ", lead %d" % int(args.lead)
     n_frames = args.frames or cfg["frames"]
     batches = cfg.get("batches", 1)
     N, cp, Kd, mod, n_sym = cfg["nfft"], cfg["cp"], cfg["Kd"], cfg["mod"], cfg["n_sym"]

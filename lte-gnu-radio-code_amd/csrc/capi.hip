@@ -391,7 +391,8 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     auto zc = make_zc(MM, root, c->compat == OFDM_COMPAT_UTSA ? MM : Ks);
     const size_t rows = size_t(c->num_ofdm_symb);
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
-    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM));
+    auto zcp = rx_zc_lane_table(N, Ks, S, zc.data());                  // lane-order copy, stored behind the sequence itself
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM) + zcp.size());
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_edf, rows * Kd);
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_tsr, 4);
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_H, size_t(2) * N);
@@ -406,6 +407,7 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     if (rc == OFDM_OK) {
         bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_zc + MM, zcp.data(), zcp.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemset(h->d_edf, 0, rows * Kd * sizeof(cf)) == hipSuccess &&
                   hipMemset(h->s_tsr, 0, 4 * sizeof(int)) == hipSuccess &&
                   hipMemset(h->s_H, 0, size_t(2) * N * sizeof(cf)) == hipSuccess &&
@@ -423,6 +425,7 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     }
     d.tw = h->d_tw;
     d.zc = h->d_zc;
+    d.zcp = h->d_zc + MM;
     h->scan_block = rx_sync_scan_block(d);
     if (h->scan_block > 0) {
         auto g = make_scan_table(N, Ks, zc);
@@ -849,7 +852,8 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     auto tw = make_twiddles(N);
     auto zc = make_zc(MM, root, Ks);                                  // FO:168-176: parity of num_synch_bins
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
-    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM));
+    auto zcp = rx_zc_lane_table(N, Ks, d.S, zc.data());
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM) + zcp.size());
     if (rc == OFDM_OK && c->rotators) rc = dev_alloc(&h->d_rot, size_t(c->n_fo) * N);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_tsr, R * 4);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_H, R * N);
@@ -871,6 +875,7 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     if (rc == OFDM_OK) {
         bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_zc + MM, zcp.data(), zcp.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   (!c->rotators ||
                    hipMemcpy(h->d_rot, c->rotators, size_t(c->n_fo) * N * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess) &&
                   hipMemset(h->t_tsr, 0, R * 4 * sizeof(int)) == hipSuccess &&
@@ -890,6 +895,7 @@ int ofdm_fo_create(const ofdm_fo_cfg* c, ofdm_fo** out) {
     }
     d.tw = h->d_tw;
     d.zc = h->d_zc;
+    d.zcp = h->d_zc + MM;
     *out = h;
     return OFDM_OK;
 }
@@ -1139,7 +1145,8 @@ int ofdm_trk_create(const ofdm_trk_cfg* c, ofdm_trk** out) {
     auto tw = make_twiddles(N);
     auto zc = make_zc(Ks, c->zc_root, Ks);                             // :123-130 parity of MM = Ks
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_tw, size_t(N));
-    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(Ks));
+    auto zcp = rx_zc_lane_table(N, Ks, 1, zc.data());
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(Ks) + zcp.size());
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_tsr, RS * 4);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_H, RS * N);
     if (rc == OFDM_OK) rc = dev_alloc(&h->t_imp, RS * N);
@@ -1152,6 +1159,7 @@ int ofdm_trk_create(const ofdm_trk_cfg* c, ofdm_trk** out) {
     if (rc == OFDM_OK) {
         bool ok = hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(h->d_zc, zc.data(), zc.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_zc + Ks, zcp.data(), zcp.size() * sizeof(cf), hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemset(h->t_tsr, 0, RS * 4 * sizeof(int)) == hipSuccess &&
                   hipMemset(h->t_H, 0, RS * N * sizeof(cf)) == hipSuccess &&
                   hipMemset(h->t_imp, 0, RS * N * sizeof(cf)) == hipSuccess &&
@@ -1168,6 +1176,7 @@ int ofdm_trk_create(const ofdm_trk_cfg* c, ofdm_trk** out) {
     }
     d.tw = h->d_tw;
     d.zc = h->d_zc;
+    d.zcp = h->d_zc + Ks;
     *out = h;
     return OFDM_OK;
 }

@@ -20,6 +20,8 @@ struct RxDev {
     int bps;                  // bits per symbol of the fused de-mapper
     const cf* tw;             // [nfft]  exp(-2 pi i j / nfft)
     const cf* zc;             // [MM]    Zadoff-Chu reference
+    const cf* zcp;            // [S][nfft] the same sequence in LANE order: zcp[LL*nfft + slot*T + t] = zc[LL*Ks + i] for the bin that
+                              //           lane t holds in FFT output register `slot` (0 for bins outside the sync list); see rx_zc_lane_table
 };
 
 // Bin list of the reference: i -> k  for  binsP(K) = ([-K/2..-1, 1..K/2] + N) % N  (SynchAndChanEst.py:38-41).

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "ofdm_device.hpp"
 
 namespace ofdm {
@@ -137,6 +138,8 @@ hipError_t launch_tx_sync_grid(const TxDev& tx, cf* grid, hipStream_t s);
 hipError_t launch_tx_time(const TxDev& tx, const TimeArgs& a, hipStream_t s);
 hipError_t launch_tx_mux(const TxDev& tx, const MuxArgs& a, hipStream_t s);
 size_t rx_lds_bytes(int nfft);
+// RxDev::zcp for a host copy of the Zadoff-Chu sequence zc[S*Ks]: [S][nfft] entries in lane / register-slot order
+std::vector<cf> rx_zc_lane_table(int nfft, int Ks, int S, const cf* zc);
 // block length of the screened sync search for this numerology (0: the preconditions do not hold, use the sequential search)
 int rx_sync_scan_block(const RxDev& rx);
 hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,

@@ -56,6 +56,22 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
         asm volatile("" : "+s"(Ks_));
         const cf* zcs = rx.zc + LL * Ks_;
         cf* ys = yscratch ? yscratch + LL * Ks_ : nullptr;
+        // The Zadoff-Chu entry of every bin this lane holds, from the LANE-ORDER copy of the table (RxDev::zcp): entry
+        // [slot*T + t], zero for bins outside the list.  One base address, sixteen independent coalesced reads in flight together.
+        // (Gathering zc[list index of bin k] through per-bin index arithmetic put 48 loop-invariant VGPRs of indices and addresses
+        // across the trial loop and made hipcc wait for every read on its own: 16 global-memory latencies per FFT.)
+        const cf* zp = rx.zcp + LL * N + t;
+        cf zt[P];
+#pragma unroll
+        for (int s = 0; s < P; ++s) zt[s] = zp[s * T];
+        // every read issued before any is consumed (one opaque use of all of them: hipcc otherwise sinks each read to its use
+        // and waits for it there)
+        if constexpr (P == 16) {
+            asm volatile("" : "+v"(zt[0]), "+v"(zt[1]), "+v"(zt[2]), "+v"(zt[3]), "+v"(zt[4]), "+v"(zt[5]), "+v"(zt[6]), "+v"(zt[7]),
+                              "+v"(zt[8]), "+v"(zt[9]), "+v"(zt[10]), "+v"(zt[11]), "+v"(zt[12]), "+v"(zt[13]), "+v"(zt[14]), "+v"(zt[15]));
+        } else {
+            asm volatile("" : "+v"(zt[0]), "+v"(zt[1]), "+v"(zt[2]), "+v"(zt[3]), "+v"(zt[4]), "+v"(zt[5]), "+v"(zt[6]), "+v"(zt[7]));
+        }
 #pragma unroll
         for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
@@ -63,20 +79,39 @@ __device__ __forceinline__ void sync_trial(const RxDev& rx, const cf* frame_iq, 
                 const int k = (t + T * j) + PL::NC * kl;
                 const int s = out_slot<N>(j, kl);
                 int in_, ip_;
-                const bool neg = bin_neg(k, Ks_, N, in_);
-                const bool pos = bin_pos(k, Ks_, ip_);
-                if (neg) {                                                              // :153-161
-                    const cf c = cmulc(v[s], zcs[in_]);
-                    Z[s] = Z[s] + c;
-                    psum += cnorm2(v[s]);
-                    if (pos) zdup = zdup + c;
-                    if (ys && active) ys[in_] = v[s];
+                const bool neg = bin_neg(k, Ks_, N, in_), pos = bin_pos(k, Ks_, ip_);   // :153-161
+                const bool used = neg || pos;
+                Z[s] = Z[s] + cmulc(v[s], zt[s]);
+                psum += used ? cnorm2(v[s]) : 0.f;
+            }
+        }
+        if (Ks_ == N) {                             // K == N lists bin N/2 twice (ofdm_chain.py:83 wiring); zcp holds its LAST
+#pragma unroll                                      // (positive-half) entry, the first (negative-half) one is added here
+            for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+                for (int kl = 0; kl < PL::RL; ++kl) {
+                    const int k = (t + T * j) + PL::NC * kl;
+                    const int s = out_slot<N>(j, kl);
+                    if (k == N / 2) {
+                        const cf c = cmulc(v[s], zcs[0]);                               // negative half: list index 0
+                        zdup = zdup + c;
+                        Z[s] = Z[s] + c;
+                        psum += cnorm2(v[s]);
+                    }
                 }
-                if (pos) {
-                    const cf c = cmulc(v[s], zcs[ip_]);
-                    Z[s] = Z[s] + c;
-                    psum += cnorm2(v[s]);
-                    if (ys && active) ys[ip_] = v[s];
+            }
+        }
+        if (ys && active) {                         // raw sync-bin values for est_synch_freq, AFTER the reads above: a store
+#pragma unroll                                      // between two table reads would order them (the pointers may alias)
+            for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+                for (int kl = 0; kl < PL::RL; ++kl) {
+                    const int k = (t + T * j) + PL::NC * kl;
+                    int in_, ip_;
+                    const bool neg = bin_neg(k, Ks_, N, in_);
+                    const bool pos = bin_pos(k, Ks_, ip_);
+                    if (neg) ys[in_] = v[out_slot<N>(j, kl)];
+                    if (pos) ys[ip_] = v[out_slot<N>(j, kl)];
                 }
             }
         }
@@ -152,7 +187,18 @@ __device__ __forceinline__ void sync_finalize(const RxDev& rx, const SyncArgs& a
     }
     wg_barrier();
     const float sc = pests * rx.inv_ls;                                                 // p_est / (S (1+1/snr)) :180-184
-#pragma unroll 1
+    // the lag de-rotation e^{+j 2pi d k/N} of this lane's 16 bins (:177): sixteen independent table reads issued together
+    // (one per loop iteration, each waited for on its own, was a third of the kernel's time in the aligned case)
+    cf rots[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) rots[q] = rx.tw[(dhats * (t + T * q)) & (N - 1)];
+    if constexpr (P == 16) {
+        asm volatile("" : "+v"(rots[0]), "+v"(rots[1]), "+v"(rots[2]), "+v"(rots[3]), "+v"(rots[4]), "+v"(rots[5]), "+v"(rots[6]), "+v"(rots[7]),
+                          "+v"(rots[8]), "+v"(rots[9]), "+v"(rots[10]), "+v"(rots[11]), "+v"(rots[12]), "+v"(rots[13]), "+v"(rots[14]), "+v"(rots[15]));
+    } else {
+        asm volatile("" : "+v"(rots[0]), "+v"(rots[1]), "+v"(rots[2]), "+v"(rots[3]), "+v"(rots[4]), "+v"(rots[5]), "+v"(rots[6]), "+v"(rots[7]));
+    }
+#pragma unroll
     for (int q = 0; q < P; ++q) {
         const int k = t + T * q;
         const cf Zk = lds[k];
@@ -160,7 +206,7 @@ __device__ __forceinline__ void sync_finalize(const RxDev& rx, const SyncArgs& a
         const bool neg = bin_neg(k, Ks, N, in_);
         const bool pos = bin_pos(k, Ks, ip_);
         const cf zd = (pos && neg) ? lds[N] : cf{0.f, 0.f};
-        const cf rot = cconj(rx.tw[(dhats * k) & (N - 1)]);                             // e^{+j 2pi d k/N}  :177
+        const cf rot = cconj(rots[q]);                                                  // e^{+j 2pi d k/N}  :177
         const cf Hn = cscale(cmul(rot, (pos && neg) ? zd : Zk), sc);
         const cf Hp = cscale(cmul(rot, (pos && neg) ? (Zk - zd) : Zk), sc);
         // chan_est1[synch_bins] = chan_est : a bin listed twice keeps its LAST (positive-half) entry :186-188
@@ -834,6 +880,36 @@ hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s) {
     OFDM_DISPATCH_N(rx.nfft, CALL)
 #undef CALL
 }
+template <int N>
+static void zc_lane_table_n(int Ks, int S, const cf* zc, std::vector<cf>& out) {
+    using PL = Plan<N>;
+    const int h = Ks / 2;
+    for (int LL = 0; LL < S; ++LL)
+        for (int t = 0; t < PL::T; ++t)
+            for (int j = 0; j < PL::C; ++j)
+                for (int kl = 0; kl < PL::RL; ++kl) {
+                    const int k = (t + PL::T * j) + PL::NC * kl;
+                    cf z = cf{0.f, 0.f};
+                    if (k >= N - h) z = zc[LL * Ks + (k - (N - h))];            // negative half of binsP(Ks)
+                    if (k >= 1 && k <= h) z = zc[LL * Ks + (h + k - 1)];        // positive half (the later entry of a bin listed twice)
+                    out[size_t(LL) * N + size_t(out_slot<N>(j, kl)) * PL::T + t] = z;
+                }
+}
+
+std::vector<cf> rx_zc_lane_table(int nfft, int Ks, int S, const cf* zc) {
+    std::vector<cf> out(size_t(S) * nfft, cf{0.f, 0.f});
+    switch (nfft) {
+        case 64: zc_lane_table_n<64>(Ks, S, zc, out); break;
+        case 128: zc_lane_table_n<128>(Ks, S, zc, out); break;
+        case 256: zc_lane_table_n<256>(Ks, S, zc, out); break;
+        case 512: zc_lane_table_n<512>(Ks, S, zc, out); break;
+        case 1024: zc_lane_table_n<1024>(Ks, S, zc, out); break;
+        case 2048: zc_lane_table_n<2048>(Ks, S, zc, out); break;
+        case 4096: zc_lane_table_n<4096>(Ks, S, zc, out); break;
+    }
+    return out;
+}
+
 int rx_sync_scan_block(const RxDev& rx) {
     switch (rx.nfft) {
         case 64: return scan_block_n<64>(rx);
