@@ -504,6 +504,9 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
     sa.htime = h->f_htime;
     sa.scan_block = h->scan_block;       // screened search where its preconditions hold (same outcome as the exhaustive one)
     sa.scan_g = h->d_scan_g;
+#ifdef OFDM_EXPERIMENTS
+    sa.stamps = h->d_stamps;
+#endif
     hipEvent_t* pev = h->ev + 3 * (h->prof_calls % ofdm_rx::PROF_RING);
     if (h->profiling) HIP_TRY(hipEventRecord(pev[0], s));
     HIP_TRY(launch_rx_sync(d, sa, s));

@@ -391,12 +391,22 @@ struct ScanGeom {
     static constexpr int QM = (T >= 256) ? 2 : (T >= 128) ? 3 : (T >= 64) ? 4 : (T >= 32) ? 6 : (Plan<N>::P < 12 ? Plan<N>::P : 12);
     static constexpr int BMAX = (QM * T < 256) ? QM * T : 256;        // longest block (trials per anchor)
     static constexpr int RMAX = (BMAX + T - 1) / T;                   // window-edge samples per lane
-    static constexpr int UNR = QM >= 8 ? 2 : 4;                       // recurrence steps per loop iteration (register budget)
-    // extra LDS per slot (cf units): dl[BMAX + UNR] | xn[BMAX] | G[QM*T + 2] | thr[BMAX + UNR floats]
-    static constexpr int DL_OFF = 0, XN_OFF = BMAX + UNR, G_OFF = XN_OFF + BMAX, THR_OFF = G_OFF + QM * T + 2;
-    static constexpr int EXTRA = THR_OFF + (BMAX + UNR + 1) / 2;
+    static constexpr int UNR = QM >= 8 ? 1 : (QM >= 6 ? 2 : 4);       // recurrence steps per loop iteration (register budget)
+    // extra LDS per slot (cf units): dl[BMAX + 2 UNR] | xn[BMAX] | BMAX zeros, then G[0 .. QM*T] | thr[BMAX + 2 UNR floats] | flag
+    static constexpr int DL_OFF = 0, XN_OFF = BMAX + 2 * UNR, GZ_OFF = XN_OFF + BMAX, G_OFF = GZ_OFF + BMAX,
+                         THR_OFF = G_OFF + QM * T + 2;
+    static constexpr int FLAG_OFF = THR_OFF + (BMAX + 2 * UNR + 1) / 2;
+    static constexpr int EXTRA = FLAG_OFF + 1;
     static constexpr size_t BYTES = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * EXTRA * sizeof(cf);
 };
+
+// u += d * g  (complex) in two packed FMAs: (d.x g.x + u.x, d.x g.y + u.y), then (d.y (-g.y) + u.x, d.y g.x + u.y)
+__device__ __forceinline__ void cfma(cf& u, cf d, cf g) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "+v"(u)
+        : "v"(d), "v"(g));
+}
 
 template <int N, int MINW = 2>
 __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev rx, SyncArgs a) {
@@ -415,8 +425,9 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     cf* extra = smem + WgLds<N>::STRIDE * SLOTS + WgLds<N>::W1_ELEMS + slot * SG::EXTRA;
     cf* xo = extra + SG::DL_OFF;          // window-edge samples leaving; overwritten by dl[i] = xn[i] - xo[i]
     cf* xn = extra + SG::XN_OFF;          // window-edge samples entering
-    cf* Gl = extra + SG::G_OFF;
+    cf* Gl = extra + SG::G_OFF;           // preceded by BMAX zero entries: alignments that are not needed yet add nothing
     float* thr = reinterpret_cast<float*>(extra + SG::THR_OFF);
+    int* cflag = reinterpret_cast<int*>(extra + SG::FLAG_OFF);
 
     std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
     load_twiddles(tw, rx.tw, t);
@@ -434,8 +445,8 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     if (a.p_count > 0 && nvalid64 > a.p_count) nvalid64 = a.p_count;
     const int nvalid = active ? int(nvalid64 < (1 << 30) ? nvalid64 : (1 << 30)) : 0;
 
-    // the table G[1 .. B + cp] -> LDS once; entry 0 is a ZERO so that out-of-range alignments add nothing, branch-free
-    for (int i = t; i <= QM * T; i += T) Gl[i] = i ? a.scan_g[i] : cf{0.f, 0.f};
+    // the table G[1 .. B + cp] -> LDS once; entries -BMAX .. 0 are ZERO: alignments behind the current trial add nothing, branch-free
+    for (int i = t - SG::BMAX; i <= QM * T; i += T) Gl[i] = i > 0 ? a.scan_g[i] : cf{0.f, 0.f};
 
     // Every iteration evaluates ONE trial exactly (the anchor at P0) and then screens the trials after it; the first flagged
     // trial becomes the next anchor, so "verification" and "anchor" are the same code.  The accepted trial is always the most
@@ -452,10 +463,25 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     const float gate_s = rx.gate_mm * (1.f - 1e-3f);
     const float thr_k = gate_s * gate_s / float(rx.MM);                // |u|^2 > thr_k * E  <=>  p_est |u| > gate_s
 
+#ifdef OFDM_EXPERIMENTS
+    unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#define SCAN_STAMP(i)                                                              \
+    do {                                                                           \
+        unsigned long long tn_;                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory"); \
+        acc[i] += unsigned(tn_ - tprev);                                           \
+        tprev = tn_;                                                               \
+    } while (0)
+#else
+#define SCAN_STAMP(i) do { } while (0)
+#endif
     int P0 = 0;
     for (;;) {
         const bool blk_on = !found && P0 < nvalid;
         if (!__syncthreads_or(blk_on ? 1 : 0)) break;
+        SCAN_STAMP(0);
         // ---- (1) anchor: exact trial at P0
         cf u[QM];
         float e0;
@@ -486,6 +512,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             }
         }
         const cf y0 = cf{red[16], red[17]}, yh = cf{red[18], red[19]};
+        SCAN_STAMP(1);                                                       // .. anchor trial
         // ---- (2) screen the trials P0+1 .. P0+nb-1 with the recurrence
         const int nb = (blk_on && !found) ? min(B, nvalid - P0) : 0;      // trials of this block (incl. the anchor)
         int cand = 0x7fffffff;
@@ -508,6 +535,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     db = db + cscale(o - n_, sgn);
                 }
             }
+            SCAN_STAMP(2);                                                   // .. window-edge loads
             // inclusive scan of the per-lane totals over the T lanes of the slot (T <= 64: inside one wave; else via LDS)
             float sw = dw, swa = wadd;
             cf sa = da, sb = db;
@@ -576,46 +604,67 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                 }
             }
             // padding read by the unrolled loop past the block's last step: adds nothing, never flags
-            for (int idx = t; idx < SG::BMAX + SG::UNR; idx += T) {
+            for (int idx = t; idx < SG::BMAX + 2 * SG::UNR; idx += T) {
                 if (idx >= nb - 1) xo[idx] = cf{0.f, 0.f};
                 if (idx >= nb) thr[idx] = 3.0e38f;
             }
+            if (t == 0) *cflag = 0x7fffffff;
             wg_barrier();
+            SCAN_STAMP(3);                                                   // .. prefix scan + thresholds
             // ---- recurrence over the steps j = 1 .. nb-1, UNR steps per iteration with all their LDS reads issued up front.
             // No barrier inside: lanes leave the loop on their own (first flagged trial, or the end of their frame's block).
+            // The first flagged trial is published in LDS (cflag) and every lane of the frame stops there: without that, only
+            // the lane that owns the flagged alignment would leave and its wave would still run to the end of the block.
             {
                 const cf* dl = xo;
-                for (int j = 1; j < nb; j += SG::UNR) {
-                    cf dd[SG::UNR], gg[SG::UNR][QM];
-                    float th[SG::UNR];
+                cf dA[SG::UNR], gA[SG::UNR][QM], dB[SG::UNR], gB[SG::UNR][QM];
+                float tA[SG::UNR], tB[SG::UNR];
+                const cf* gbase = Gl + t + 1;                            // G index of alignment t + T*q at trial j: (t + 1 - j) + T*q
+                auto fetch = [&](int j, cf (&dd)[SG::UNR], float (&th)[SG::UNR], cf (&gg)[SG::UNR][QM]) {
 #pragma unroll
                     for (int s_ = 0; s_ < SG::UNR; ++s_) {
                         dd[s_] = dl[j + s_ - 1];
                         th[s_] = thr[j + s_];
 #pragma unroll
-                        for (int q = 0; q < QM; ++q) {
-                            const int idx = t + T * q - (j + s_) + 1;    // G index; the lag of alignment t + T*q at that trial is idx - 1
-                            gg[s_][q] = Gl[unsigned(idx - 1) < unsigned(QM * T) ? idx : 0];
-                        }
+                        for (int q = 0; q < QM; ++q) gg[s_][q] = gbase[T * q - (j + s_)];   // index >= -BMAX: zeros below 1
                     }
+                };
+                auto step = [&](int j, const cf (&dd)[SG::UNR], const float (&th)[SG::UNR], const cf (&gg)[SG::UNR][QM]) {
                     int first = SG::UNR;
 #pragma unroll
                     for (int s_ = 0; s_ < SG::UNR; ++s_) {
                         bool h = false;
 #pragma unroll
                         for (int q = 0; q < QM; ++q) {
-                            const int lag = t + T * q - (j + s_);
-                            u[q] = u[q] + cmul(dd[s_], gg[s_][q]);
-                            h |= (unsigned(lag) <= unsigned(cp)) && (cnorm2(u[q]) > th[s_]);
+                            cfma(u[q], dd[s_], gg[s_][q]);
+                            h |= (unsigned(t + T * q - (j + s_)) <= unsigned(cp)) && (cnorm2(u[q]) > th[s_]);
                         }
                         if (h && first == SG::UNR) first = s_;
                     }
                     if (first < SG::UNR) {
                         cand = j + first;
-                        break;
+                        atomicMin(cflag, cand);
                     }
+                };
+                int j = 1;
+                int lim = nb;
+                if (j < lim) fetch(j, dA, tA, gA);
+                while (j < lim) {
+                    fetch(j + SG::UNR, dB, tB, gB);                      // reads past the block's end hit the padding
+                    const int seen = *cflag;
+                    step(j, dA, tA, gA);
+                    j += SG::UNR;
+                    lim = min(lim, seen);
+                    if (cand != 0x7fffffff || j >= lim) break;
+                    fetch(j + SG::UNR, dA, tA, gA);
+                    const int seen2 = *cflag;
+                    step(j, dB, tB, gB);
+                    j += SG::UNR;
+                    lim = min(lim, seen2);
+                    if (cand != 0x7fffffff) break;
                 }
             }
+            SCAN_STAMP(4);                                                   // .. recurrence loop
             // first flagged trial of the slot
 #pragma unroll
             for (int mk = W >> 1; mk >= 1; mk >>= 1) cand = min(cand, __shfl_xor(cand, mk, W));
@@ -632,8 +681,18 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         }
         // the first flagged trial is the next anchor (evaluated exactly there); an unflagged block is skipped whole
         if (nb > 0) P0 += (cand < nb) ? cand : nb;
+        SCAN_STAMP(5);                                                       // .. candidate reduction
     }
+    SCAN_STAMP(6);
     sync_finalize<N>(rx, a, frame, active, found, Phit, Zs, zdups, pests, ms, dhats, lds, tw, w1tab, t, ysc);
+#ifdef OFDM_EXPERIMENTS
+    SCAN_STAMP(7);                                                           // .. finalize
+    if (a.stamps && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.stamps[int64_t(blockIdx.x) * 8 + i] = acc[i];
+    }
+#endif
+#undef SCAN_STAMP
 }
 
 // ------------------------------------------------------------------------------------------ standalone de-mapper
@@ -849,7 +908,7 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
             return hipErrorInvalidValue;
         // register budget: 168 VGPRs (3 waves per SIMD) costs ~23 spills for one frame per workgroup (N >= 1024); the packed small
         // sizes keep a second copy of Z and get 256
-        hipLaunchKernelGGL((rx_sync_scan_kernel<N, (N >= 1024 ? 3 : 2)>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
+        hipLaunchKernelGGL((rx_sync_scan_kernel<N, 2>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
         return hipGetLastError();
     }
     // 3 waves per SIMD (168 VGPRs, a few spills off the trial path): 0.14 ms instead of 0.21 ms per 4369-frame launch; the

@@ -3,12 +3,12 @@
 Every frame is preceded by its own random lead of 0..L-1 noise samples, so the search of every frame ends at a different
 trial, deep inside the frame or -- with a trial cap -- not at all.  `time_synch_ref` must equal the oracle's (position and lag
 exactly, int(peak) within 1), the equalised symbols must match at 1e-5, and the screened search (anchor trials evaluated
-exactly, the trials between them screened by the sliding recurrence) must return byte for byte what the exhaustive
-trial-by-trial search returns."""
+exactly, the trials between them screened by the sliding recurrence) must take the same decisions and return the same arrays (to
+the last bits: 2e-6 of the peak) as the exhaustive trial-by-trial search."""
 import numpy as np
 import pytest
 
-from conftest import assert_close
+from conftest import assert_close, relerr
 from oracle import ofdm_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -70,8 +70,12 @@ def test_random_leads_match_the_oracle(om, N, cp, Kd, n_sym, n_frames, sigma, ma
     rx = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 30, 0.7)
     eq_s, b_s, tsr_s, H_s = _run(om, rx, iq, Kd, exhaustive=False)
     eq_x, b_x, tsr_x, H_x = _run(om, rx, iq, Kd, exhaustive=True)
-    assert np.array_equal(tsr_s, tsr_x) and np.array_equal(eq_s.view(np.uint32), eq_x.view(np.uint32))
-    assert np.array_equal(b_s, b_x) and np.array_equal(H_s.view(np.uint32), H_x.view(np.uint32))
+    # same decisions; the arrays agree to the last bits (two separately compiled kernels around the same trial function: fused
+    # multiply-adds may be contracted differently, so "bit for bit" is not promised -- 2e-6 of the peak is)
+    assert np.array_equal(tsr_s, tsr_x) and np.array_equal(b_s, b_x)
+    fin = np.isfinite(eq_x)
+    assert np.array_equal(fin, np.isfinite(eq_s))
+    assert relerr(np.where(fin, eq_s, 0), np.where(fin, eq_x, 0)) < 2e-6 and relerr(H_s, H_x) < 2e-6
     rows = [r for r in range(n_sym) if r % 4 != 3]
     hits = set()
     for f in range(n_frames):
@@ -103,8 +107,10 @@ def test_zero_leads_noise_only_frames_and_trial_cap(om):
     for cap in (0, 150):
         s = _run(om, rx, iq, Kd, exhaustive=False, max_trials=cap)
         x = _run(om, rx, iq, Kd, exhaustive=True, max_trials=cap)
-        for a, b in zip(s, x):
-            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+        assert np.array_equal(s[2], x[2]) and np.array_equal(s[1], x[1])
+        for a, b in ((s[0], x[0]), (s[3], x[3])):
+            assert np.array_equal(np.isfinite(a), np.isfinite(b))
+            assert relerr(np.nan_to_num(a), np.nan_to_num(b)) < 2e-6
         tsr = s[2]
         assert tsr[5, 3] == 0 and not tsr[5].any() and not s[0][5].any()
         for f in (0, 1, 2, 3, 4, 6, 7):
