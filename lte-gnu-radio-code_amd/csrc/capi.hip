@@ -8,6 +8,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -426,6 +427,9 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     d.tw = h->d_tw;
     d.zc = h->d_zc;
     d.zcp = h->d_zc + MM;
+#ifdef OFDM_EXPERIMENTS
+    if (const char* ev = std::getenv("OFDM_EXP_VARIANT")) h->variant = std::atoi(ev);   // run a whole test suite on one variant
+#endif
     h->scan_block = rx_sync_scan_block(d);
     if (h->scan_block > 0) {
         auto g = make_scan_table(N, Ks, zc);

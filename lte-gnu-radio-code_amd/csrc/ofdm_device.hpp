@@ -52,6 +52,19 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// LDS ordering inside ONE wavefront: LDS operations of a wave execute in order, so when a symbol is owned by a single wave
+// (T <= 64) its exchanges need no s_barrier at all -- only the counter wait and a compiler fence.
+__device__ __forceinline__ void wave_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void slot_sync() {
+    if constexpr (WAVE_LOCAL)
+        wave_fence();
+    else
+        wg_barrier();
+}
+
 // Sum over all T lanes of one symbol.  `red` = 8 floats of LDS scratch per symbol slot (only used when T > 64).
 // Contains one workgroup barrier when T > 64 (all lanes of the workgroup must call it).
 template <int T>
@@ -132,15 +145,16 @@ __device__ __forceinline__ const cf* wg_init_w1(cf* smem, const cf* __restrict__
 // On return lane t holds bin k = (t + T*j) + NC*kl in v[out_slot<N>(j,kl)].
 // Contains 1 (2-pass) or 3 (3-pass) workgroup barriers; the symbol's LDS region may still be read by
 // other lanes on return, so the caller must barrier before overwriting it.
-template <int N, class TW>
+template <int N, class TW, bool WAVE_LOCAL = false>
 __device__ __forceinline__ void wg_fft(cf (&v)[Plan<N>::P], cf* lds, const TW& tw, const cf* w1tab, int t) {
+    static_assert(!WAVE_LOCAL || Plan<N>::T <= 64, "wave-local synchronisation needs one wave per symbol");
     fft_pass0_store<N>(v, lds, tw, t);
-    wg_barrier();
+    slot_sync<WAVE_LOCAL>();
     if constexpr (Plan<N>::THREE) {
         fft_pass1_load<N>(v, lds, t);
-        wg_barrier();
+        slot_sync<WAVE_LOCAL>();
         fft_pass1_store<N>(v, lds, w1tab, t);
-        wg_barrier();
+        slot_sync<WAVE_LOCAL>();
     }
     fft_last_load<N>(v, lds, t);
     fft_last_dft<N>(v);

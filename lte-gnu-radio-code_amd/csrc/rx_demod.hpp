@@ -243,6 +243,9 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     // wave-uniform, and saying so moves it from VGPRs / VALU to SGPRs / SALU
     const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
     const int t = tid % T;
+    // One wave per symbol (T <= 64): the waves of a workgroup are independent symbols that only share the read-only gain copy
+    // and twiddle table, so every per-symbol barrier is a wave-local fence (LDS is in order per wave).
+    constexpr bool WL = T <= 64;
     cf* smem = reinterpret_cast<cf*>(smem_raw);
     cf* lds = smem + slot * WgLds<N>::STRIDE;
     float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
@@ -335,6 +338,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     // symbol's time) -- the HBM latency (~25 % of a wave's time when exposed) is hidden at no register cost.
     Sym cur = sym_of(0);
     if constexpr (PIPE) load_sym(cur);
+    if constexpr (WL) wg_barrier();              // the shared gain copy and twiddle table: published once, read-only afterwards
     for (int it = 0; it < n_iter; ++it) {
         if constexpr (!PIPE) {
             cur = sym_of(it);
@@ -359,9 +363,9 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
             fft_last_load<N>(v, lds, t);
             fft_last_dft<N>(v);
         } else {
-            wg_fft<N>(v, lds, tw, w1tab, t);                             // :230
+            wg_fft<N, decltype(tw), WL>(v, lds, tw, w1tab, t);           // :230
         }
-        wg_barrier();                                                    // exchange region -> staging region
+        slot_sync<WL>();                                                 // exchange region -> staging region
 
         // Re-materialise Kd per symbol so hipcc does not hoist 16 per-slot list offsets into VGPRs held across the loop.
         int Kd_ = Kd;
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                     if ((t + T * j) + PL::NC * kl == N / 2) lds[N - 1] = v[out_slot<N>(j, kl)];
             }
         }
-        wg_barrier();
+        slot_sync<WL>();
 
         stamp(4);                                                        // .. pass 2 + scatter into list order
         if constexpr (PIPE) {
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
             }
         }
         stamp(6);                                                        // .. equalise + de-map + stores issued
-        wg_barrier();                                                    // staging region free for the next symbol
+        slot_sync<WL>();                                                 // staging region free for the next symbol
         stamp(7);                                                        // .. loop-end barrier
     }
     if constexpr (STAMP) {
