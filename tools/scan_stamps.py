@@ -29,7 +29,7 @@ for lead in leads:
         rxe.demod_frames(d_rx, n_frames, fl, fl, None, d_bits, om.BITS_PACKED, None, st)
     torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.int64)
-    print("lead %s: sync kernel %.4f ms; mean cycles per workgroup (100 MHz s_memtime ticks x?):" % (lead, rxe.kernel_ms()[0]))
+    print("lead %s: sync kernel %.4f ms; mean shader-clock cycles per workgroup and phase (s_memtime):" % (lead, rxe.kernel_ms()[0]))
     for i, n in enumerate(names):
         print("   %-14s %10.0f" % (n, s[:, i].mean()))
     print("   total          %10.0f" % s.sum(1).mean())
