@@ -232,7 +232,7 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false, bool HG = false, bool CT = false>
+template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false, bool HG = false, bool CT = (Plan<N>::R0 == 16), bool PSE = true>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
@@ -310,6 +310,9 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         sy.orow = int64_t(frame) * a.rows_per_frame + (p * a.row_stride_pat + n_);
         return sy;
     };
+    // PSE: the per-symbol power (:233) is summed from the FFT output REGISTERS while the bins are scattered into list order, and its
+    // per-wave partials cross the scatter's own barrier -- no separate LDS read pass over the list and no barrier of its own
+    // (PSE = false keeps the read-back form for A/B timing in the experiment build).
     cf v[P];
     auto load_sym = [&](const Sym& sy) {
         if (sy.compute && sy.start >= 0 && sy.start + N <= a.frame_len) {
@@ -374,6 +377,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         // :232 gather into bin-list order: negative half i = k-(N-Kd/2), positive half i = Kd/2+k-1.
         // Unlisted bins fall past the list (i in [Kd, N-2]) and DC is parked at index N (< LDS_ELEMS): no branches.
         const int off_neg = hk - N, off_pos = hk - 1;
+        float pse = 0.f;
 #pragma unroll
         for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
@@ -382,6 +386,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 int i = k + ((k >= N - hk) ? off_neg : off_pos);
                 if (j == 0 && kl == 0) i = (k == 0) ? N : i;             // only this slot can hold DC
                 lds[i] = v[out_slot<N>(j, kl)];
+                if constexpr (PSE) pse += (unsigned(i) < unsigned(Kd_)) ? cnorm2(v[out_slot<N>(j, kl)]) : 0.f;
             }
         }
         if (Kd_ == N) {                                                  // K == N lists bin N/2 twice (ofdm_chain.py:83 wiring)
@@ -389,7 +394,16 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
             for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
                 for (int kl = 0; kl < PL::RL; ++kl)
-                    if ((t + T * j) + PL::NC * kl == N / 2) lds[N - 1] = v[out_slot<N>(j, kl)];
+                    if ((t + T * j) + PL::NC * kl == N / 2) {
+                        lds[N - 1] = v[out_slot<N>(j, kl)];
+                        if constexpr (PSE) pse += cnorm2(v[out_slot<N>(j, kl)]);
+                    }
+            }
+        }
+        if constexpr (PSE) {
+            pse = lanes_sum<T>(pse);
+            if constexpr (T > 64) {
+                if ((t & 63) == 0) red[t >> 6] = pse;
             }
         }
         slot_sync<WL>();
@@ -399,30 +413,39 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
             cur = sym_of(it + 1);
             load_sym(cur);                                               // next symbol: in flight until the next FFT
         }
-        // each lane owns 4 consecutive list entries per q: 16 B LDS reads (read twice: power sum now, output below)
         float psum = 0.f;
+        if constexpr (PSE) {
+            if constexpr (T > 64) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int idx = 4 * (t + T * q);
-            const float4 a01 = *reinterpret_cast<const float4*>(lds + idx);
-            const float4 a23 = *reinterpret_cast<const float4*>(lds + idx + 2);
-            const float p4[4] = {a01.x * a01.x + a01.y * a01.y, a01.z * a01.z + a01.w * a01.w,
-                                 a23.x * a23.x + a23.y * a23.y, a23.z * a23.z + a23.w * a23.w};
-            if (4 * T * (q + 1) <= Kd_) {                                // whole wavefront row inside the list (uniform)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) psum += p4[e];
+                for (int w = 0; w < T / 64; ++w) psum += red[w];
             } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) psum += (idx + e < Kd_) ? p4[e] : 0.f;
+                psum = pse;
             }
-        }
-        psum = lanes_sum<T>(psum);                                       // :233 sum |x|^2 over the Kd listed bins
-        if constexpr (T > 64) {
-            if ((t & 63) == 0) red[t >> 6] = psum;
-            wg_barrier();
-            psum = 0.f;
+        } else {
+            // each lane owns 4 consecutive list entries per q: 16 B LDS reads (read twice: power sum now, output below)
 #pragma unroll
-            for (int w = 0; w < T / 64; ++w) psum += red[w];
+            for (int q = 0; q < Q; ++q) {
+                const int idx = 4 * (t + T * q);
+                const float4 a01 = *reinterpret_cast<const float4*>(lds + idx);
+                const float4 a23 = *reinterpret_cast<const float4*>(lds + idx + 2);
+                const float p4[4] = {a01.x * a01.x + a01.y * a01.y, a01.z * a01.z + a01.w * a01.w,
+                                     a23.x * a23.x + a23.y * a23.y, a23.z * a23.z + a23.w * a23.w};
+                if (4 * T * (q + 1) <= Kd_) {                            // whole wavefront row inside the list (uniform)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) psum += p4[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) psum += (idx + e < Kd_) ? p4[e] : 0.f;
+                }
+            }
+            psum = lanes_sum<T>(psum);                                   // :233 sum |x|^2 over the Kd listed bins
+            if constexpr (T > 64) {
+                if ((t & 63) == 0) red[t >> 6] = psum;
+                wg_barrier();
+                psum = 0.f;
+#pragma unroll
+                for (int w = 0; w < T / 64; ++w) psum += red[w];
+            }
         }
         const float scale = sqrtf(float(Kd_) / psum);                    // :233 p_est0
         stamp(5);                                                        // .. list read + power sum
@@ -527,10 +550,14 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 5) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 6) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 7) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 8) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 4, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant >= 1 && a.variant <= 9 && a.variant != 4) return hipGetLastError();
+            // 10: round-1 form (lane twiddles in VGPRs, power sum read back from LDS); 11: compact twiddles only; 12: early power sum only
+            if (a.variant == 10) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 11) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, true, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant == 12) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            if (a.variant >= 10 && a.variant <= 12) return hipGetLastError();
+            if (a.variant >= 1 && a.variant <= 9 && a.variant != 4 && a.variant != 7) return hipGetLastError();
         }
     }
 #endif

@@ -13,5 +13,11 @@ for CFG in "$@"; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $ARGS > $OUT/kt.json 2> $OUT/kt.err)
   (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err)
   (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.json 2> $OUT/write.err)
+  if [ "${PROFILE_SQ:-0}" = "1" ]; then
+    (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $OUT/sq1 -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/sq1.err)
+    (cd /tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq2 -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/sq2.err)
+    (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq3 -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/sq3.err)
+  fi
   echo "$CFG: $(tail -c 300 $OUT/kt.json | head -c 300)"
 done
+# optional SQ counter passes (instruction mix, LDS bank conflicts, wave cycles) for the FIRST config: PROFILE_SQ=1 tools/run_profiles.sh ...
