@@ -3,7 +3,8 @@
 import collections, csv, glob, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+    import os
+    for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if "ofdm::" in r["Kernel_Name"]:
                 agg[r["Kernel_Name"][:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -25,9 +25,9 @@ import bench  # noqa: E402
 
 
 def pmc(dirname, counter):
-    files = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
     agg = collections.defaultdict(list)
-    for f in files:
+    for f in files:                                  # the newest run only (gpurun merges successive runs into the same tree)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -42,7 +42,7 @@ def main():
     out = {}
     for cfg in cfgs:
         base = os.path.join(ROOT, "gpurun_out", tag, cfg)
-        ks = glob.glob(os.path.join(base, "kt", "**", "*kernel_stats.csv"), recursive=True)[0]
+        ks = sorted(glob.glob(os.path.join(base, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
         shutil.copy(ks, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
         line = json.loads(open(os.path.join(base, "kt.json")).read().strip().splitlines()[-1])
         fe, wr = pmc(os.path.join(base, "fetch"), "FETCH_SIZE"), pmc(os.path.join(base, "write"), "WRITE_SIZE")
