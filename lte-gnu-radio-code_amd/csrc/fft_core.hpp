@@ -134,7 +134,15 @@ struct Plan {
     static constexpr int C = P / RL;                       // last-pass DFTs per lane
     static constexpr int NC = N / RL;                      // bins k = c + NC*kl
     static constexpr int LDS_A = THREE ? 16 * (T + 2) : 0;  // exchange A elements
-    static constexpr int LDS_B = NC * (RL + 1);             // exchange B elements
+    // Exchange B: rows of RL elements.  Padded to RL+1 -- or, where a third of a CU's LDS hangs on 1.8 KB (4096-pt: three
+    // workgroups per CU instead of two), unpadded with the column ROTATED by the row: element (c, n) at c*RL + ((n + c + c/16) % RL).
+    // Both forms are conflict-free for the ds_write_b64 of pass 1 (16-lane groups) and the ds_read_b64 of the last pass (32-lane
+    // groups); tests/test_fft_core_host.py checks the bank rule on the index functions themselves.
+    static constexpr bool B_SWZ = THREE && RL == 16;
+    static constexpr int LDS_B = B_SWZ ? NC * RL : NC * (RL + 1);   // exchange B elements
+    // pass-1 twiddle table: all 15 powers per n2 (16*RL entries), or only W^1, W^2, W^4, W^8 (4*RL entries, 4096-pt: LDS again)
+    static constexpr bool W1_COMPACT = B_SWZ;
+    static constexpr int W1_ELEMS = THREE ? (W1_COMPACT ? 4 * RL : 16 * RL) : 0;
     static constexpr int LDS_ELEMS = (LDS_A > LDS_B ? LDS_A : LDS_B) > N ? (LDS_A > LDS_B ? LDS_A : LDS_B) : N;
     static constexpr int SLOTS = (T >= 64) ? 1 : 64 / T;   // symbols handled side by side in one workgroup
     static constexpr int WG = T * SLOTS;                   // workgroup size (>= 64)
@@ -171,10 +179,63 @@ OFDM_HD void load_twiddles(CompactTwiddles<N>& tw, const cf* __restrict__ table,
     tw.w8 = table[(8 * t) & (N - 1)];
 }
 
-// entry e = n2*16 + k1 of the pass-1 table (3-pass plans: e < 16*RL)
+// exchange B index of element (row c, column n)
+template <int N>
+OFDM_HD int b_index(int c, int n) {
+    using PL = Plan<N>;
+    if constexpr (PL::B_SWZ)
+        return c * PL::RL + ((n + c + (c >> 4)) & (PL::RL - 1));
+    else
+        return c * (PL::RL + 1) + n;
+}
+
+// pass-1 table W_N^(16*k1*n2): entry e = n2*16 + k1 (3-pass plans: e < 16*RL), or compact e = n2*4 + log2(k1), k1 in {1,2,4,8}
 template <int N>
 OFDM_HD cf w1_entry(const cf* __restrict__ table, int e) {
-    return table[(16 * (e & 15) * (e >> 4)) & (N - 1)];
+    if constexpr (Plan<N>::W1_COMPACT)
+        return table[(16 * (1 << (e & 3)) * (e >> 2)) & (N - 1)];
+    else
+        return table[(16 * (e & 15) * (e >> 4)) & (N - 1)];
+}
+
+// v[bitrev(k,16)] *= W^k for k = 1..15 with only W^1, W^2, W^4, W^8 given: the other eleven are products formed right where
+// they are used (at most two temporaries live).
+template <int N>
+OFDM_HD void apply_compact_twiddles(cf (&v)[Plan<N>::P], const CompactTwiddles<N>& twc) {
+    constexpr int R = 16;
+    CompactTwiddles<N> tw = twc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque copies: without this the products below are loop-invariant and hipcc hoists all eleven back into VGPRs
+    asm volatile("" : "+v"(tw.w1), "+v"(tw.w2), "+v"(tw.w4), "+v"(tw.w8));
+#endif
+#define OFDM_V(k) v[bitrev(k, R)]
+    cmul3(OFDM_V(1), tw.w1, OFDM_V(2), tw.w2, OFDM_V(4), tw.w4);
+    OFDM_V(8) = cmul(OFDM_V(8), tw.w8);
+    {
+        cf a = cmul(tw.w1, tw.w2);                 // W^3
+        OFDM_V(3) = cmul(OFDM_V(3), a);
+        cf b = cmul(a, tw.w8);                     // W^11
+        OFDM_V(11) = cmul(OFDM_V(11), b);
+        a = cmul(a, tw.w4);                        // W^7
+        OFDM_V(7) = cmul(OFDM_V(7), a);
+        a = cmul(a, tw.w8);                        // W^15
+        OFDM_V(15) = cmul(OFDM_V(15), a);
+        a = cmul(tw.w1, tw.w4);                    // W^5
+        OFDM_V(5) = cmul(OFDM_V(5), a);
+        a = cmul(a, tw.w8);                        // W^13
+        OFDM_V(13) = cmul(OFDM_V(13), a);
+        a = cmul(tw.w2, tw.w4);                    // W^6
+        OFDM_V(6) = cmul(OFDM_V(6), a);
+        a = cmul(a, tw.w8);                        // W^14
+        OFDM_V(14) = cmul(OFDM_V(14), a);
+        a = cmul(tw.w1, tw.w8);                    // W^9
+        OFDM_V(9) = cmul(OFDM_V(9), a);
+        a = cmul(tw.w2, tw.w8);                    // W^10
+        OFDM_V(10) = cmul(OFDM_V(10), a);
+        a = cmul(tw.w4, tw.w8);                    // W^12
+        OFDM_V(12) = cmul(OFDM_V(12), a);
+    }
+#undef OFDM_V
 }
 
 // ------------------------------------------------------------------------------------------ passes
@@ -186,39 +247,7 @@ OFDM_HD void fft_pass0_store(cf (&v)[Plan<N>::P], cf* lds, const CompactTwiddles
     dft_dif<16, 0, 1, PL::P>(v);
     constexpr int row = PL::THREE ? (PL::T + 2) : (PL::RL + 1);
     constexpr int R = 16;
-    CompactTwiddles<N> tw = twc;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // opaque copies: without this the products below are loop-invariant and hipcc hoists all eleven back into VGPRs
-    asm volatile("" : "+v"(tw.w1), "+v"(tw.w2), "+v"(tw.w4), "+v"(tw.w8));
-#endif
-#define OFDM_V(k) v[bitrev(k, R)]
-    cmul3(OFDM_V(1), tw.w1, OFDM_V(2), tw.w2, OFDM_V(4), tw.w4);
-    OFDM_V(8) = cmul(OFDM_V(8), tw.w8);
-    {
-        cf a = cmul(tw.w1, tw.w2);                 // W^3t
-        OFDM_V(3) = cmul(OFDM_V(3), a);
-        cf b = cmul(a, tw.w8);                     // W^11t
-        OFDM_V(11) = cmul(OFDM_V(11), b);
-        a = cmul(a, tw.w4);                        // W^7t
-        OFDM_V(7) = cmul(OFDM_V(7), a);
-        a = cmul(a, tw.w8);                        // W^15t
-        OFDM_V(15) = cmul(OFDM_V(15), a);
-        a = cmul(tw.w1, tw.w4);                    // W^5t
-        OFDM_V(5) = cmul(OFDM_V(5), a);
-        a = cmul(a, tw.w8);                        // W^13t
-        OFDM_V(13) = cmul(OFDM_V(13), a);
-        a = cmul(tw.w2, tw.w4);                    // W^6t
-        OFDM_V(6) = cmul(OFDM_V(6), a);
-        a = cmul(a, tw.w8);                        // W^14t
-        OFDM_V(14) = cmul(OFDM_V(14), a);
-        a = cmul(tw.w1, tw.w8);                    // W^9t
-        OFDM_V(9) = cmul(OFDM_V(9), a);
-        a = cmul(tw.w2, tw.w8);                    // W^10t
-        OFDM_V(10) = cmul(OFDM_V(10), a);
-        a = cmul(tw.w4, tw.w8);                    // W^12t
-        OFDM_V(12) = cmul(OFDM_V(12), a);
-    }
-#undef OFDM_V
+    apply_compact_twiddles<N>(v, twc);
 #pragma unroll
     for (int k0 = 0; k0 < R; ++k0) lds[k0 * row + t] = v[bitrev(k0, R)];
 }
@@ -260,12 +289,21 @@ OFDM_HD void fft_pass1_store(cf (&v)[Plan<N>::P], cf* lds, const cf* w1tab, int 
     using PL = Plan<N>;
     const int n2 = t >> 4, k0 = t & 15;
     dft_dif<16, 0, 1, PL::P>(v);
+    if constexpr (PL::W1_COMPACT) {
+        CompactTwiddles<N> tw;
+        tw.w1 = w1tab[n2 * 4 + 0];
+        tw.w2 = w1tab[n2 * 4 + 1];
+        tw.w4 = w1tab[n2 * 4 + 2];
+        tw.w8 = w1tab[n2 * 4 + 3];
+        apply_compact_twiddles<N>(v, tw);
+    } else {
 #pragma unroll
-    for (int k1 = 1; k1 < 16; k1 += 3)
-        cmul3(v[bitrev(k1, 16)], w1tab[n2 * 16 + k1], v[bitrev(k1 + 1, 16)], w1tab[n2 * 16 + k1 + 1], v[bitrev(k1 + 2, 16)],
-              w1tab[n2 * 16 + k1 + 2]);
+        for (int k1 = 1; k1 < 16; k1 += 3)
+            cmul3(v[bitrev(k1, 16)], w1tab[n2 * 16 + k1], v[bitrev(k1 + 1, 16)], w1tab[n2 * 16 + k1 + 1], v[bitrev(k1 + 2, 16)],
+                  w1tab[n2 * 16 + k1 + 2]);
+    }
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) lds[(k1 * 16 + k0) * (PL::RL + 1) + n2] = v[bitrev(k1, 16)];
+    for (int k1 = 0; k1 < 16; ++k1) lds[b_index<N>(k1 * 16 + k0, n2)] = v[bitrev(k1, 16)];
 }
 
 // last pass: loads, transforms; afterwards bin k = (t + T*j) + NC*kl sits in v[j*RL + bitrev(kl,RL)].
@@ -276,7 +314,7 @@ OFDM_HD void fft_last_load(cf (&v)[Plan<N>::P], const cf* lds, int t) {
     for (int j = 0; j < PL::C; ++j) {
         const int c = t + PL::T * j;
 #pragma unroll
-        for (int n = 0; n < PL::RL; ++n) v[j * PL::RL + n] = lds[c * (PL::RL + 1) + n];
+        for (int n = 0; n < PL::RL; ++n) v[j * PL::RL + n] = lds[b_index<N>(c, n)];
     }
 }
 

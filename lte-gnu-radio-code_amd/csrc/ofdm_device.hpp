@@ -126,7 +126,7 @@ struct WgLds {
     static constexpr int ELEMS = Plan<N>::LDS_ELEMS + (Plan<N>::LDS_ELEMS & 1);
     static constexpr int RED_CF = 12;                                 // 12 cf = 24 dwords of scratch (16 reductions + 8 spare)
     static constexpr int STRIDE = ELEMS + RED_CF;                     // cf units, even -> 16 B aligned
-    static constexpr int W1_ELEMS = Plan<N>::THREE ? 16 * Plan<N>::RL : 0;
+    static constexpr int W1_ELEMS = Plan<N>::W1_ELEMS;
     static constexpr size_t BYTES = (size_t(STRIDE) * Plan<N>::SLOTS + W1_ELEMS) * sizeof(cf);
 };
 

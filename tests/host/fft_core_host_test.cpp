@@ -23,7 +23,7 @@ int run(const char* fin, const char* fout) {
     std::vector<LaneTwiddles<N>> tw(PL::T);
     std::vector<cf> w1tab(16 * 16);
     if constexpr (PL::THREE)
-        for (int e = 0; e < 16 * PL::RL; ++e) w1tab[e] = w1_entry<N>(tab.data(), e);
+        for (int e = 0; e < PL::W1_ELEMS; ++e) w1tab[e] = w1_entry<N>(tab.data(), e);
     std::vector<cf> regs(PL::T * PL::P);
     auto V = [&](int t) -> cf(&)[PL::P] { return *reinterpret_cast<cf(*)[PL::P]>(&regs[t * PL::P]); };
     for (int t = 0; t < PL::T; ++t) load_twiddles<N>(tw[t], tab.data(), t);
