@@ -7,11 +7,11 @@
 //
 // Data flow per symbol (N = 2048: T = 128 lanes = 2 waves, 16 points per lane):
 //   HBM --16 x 8 B/lane coalesced--> VGPR --radix16--> LDS A --radix16--> LDS B --radix8--> VGPR (bins, lane ~ bin)
-//   --scatter into the reference's bin-list order--> LDS --4 consecutive list entries per lane (16 B reads)-->
-//   power sum (wave shuffle + LDS) --> x * sqrt(Kd/P) * gain[i] --> 16 B/lane stores (+ packed bits)
-// The frame's Kd gains (equaliser * lag de-rotation, written by rx_sync_kernel) are copied into LDS once per
-// chunk of symbols.  A symbol is read from HBM once and written once: the kernel is HBM-bound by design,
-// everything else is about keeping the VALU/LDS instruction stream short enough to stay under that bound.
+//   --scatter into the reference's bin-list order (LDS), the power of the listed bins summed from the registers on the way-->
+//   4 consecutive list entries per lane (16 B reads) --> x * sqrt(Kd/P) * gain[i] --> 16 B/lane stores (+ packed bits)
+// The frame's Kd gains (equaliser * lag de-rotation, written by the sync kernel) are copied into LDS once per
+// chunk of symbols.  A symbol is read from HBM once and written once: the kernel is HBM-bound by design; DESIGN.md 4.1 has
+// the measurements of what does and does not move its time.
 //
 // MOD   bits per symbol of the fused de-mapper (1,2,4,6)           } compile-time: the per-element
 // BMODE 0 = no bits, 1 = packed MSB-first, 2 = one bit per byte      } decision code has no runtime switches
@@ -220,8 +220,6 @@ __device__ __forceinline__ void store_bits(uint8_t* bits, int64_t sym0, const cf
 //       share one LDS copy of the frame's gains and one pass-1 twiddle table: at N = 2048, NS = 2 brings the LDS
 //       cost to 23.8 KB per symbol in flight -> 6 symbols per CU instead of 5 (occupancy is what bounds this kernel:
 //       2/3/4/5 workgroups per CU measured 4.13/3.13/2.65/2.22 ms).
-// GLDS  true: the frame's gains are copied to LDS once per chunk; false: re-read from global memory per symbol
-// NT    true: the once-touched IQ stream is loaded / the outputs are stored with the non-temporal hint
 template <int N>
 struct DemodGeom {
     static constexpr int T = Plan<N>::T;
@@ -232,8 +230,27 @@ struct DemodGeom {
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
-template <int N, int MOD, int BMODE, int MINW, bool GLDS = true, bool NT = false, bool ASMB = true, bool STAMP = false, bool PIPE = true, bool L2IN = false, bool ROT = false, bool HG = false, bool CT = (Plan<N>::R0 == 16), bool PSE = true>
+// Kernel build flags.  The product library instantiates FLAGS = 0 (batch and stream paths), DF_ROT (CFO receiver) and DF_HG
+// (tracker receiver) only; every other bit exists for the A/B timing and stamping builds of the experiment library.
+enum DemodFlags : unsigned {
+    DF_ROT = 1u << 0,            // every window is multiplied by a carrier-offset rotator (SynchEstAndFO.py:339)
+    DF_HG = 1u << 1,             // a frame is demodulated iff the host set its guard flag (tracker receiver)
+    DF_GAINS_GLOBAL = 1u << 2,   // gains re-read from global memory per symbol instead of one LDS copy per chunk
+    DF_NT = 1u << 3,             // non-temporal hint on the stream loads and the output stores
+    DF_GENERIC_BITS = 1u << 4,   // plain C++ bit packing instead of the v_cmp / v_addc form
+    DF_STAMP = 1u << 5,          // s_memtime stamps per phase (diagnostic, never timed)
+    DF_NO_PIPE = 1u << 6,        // next symbol's loads issued at the loop top instead of right after the scatter
+    DF_L2_INPUT = 1u << 7,       // every workgroup reads frame (blockIdx % 8): cache-resident input, WRONG results, timing only
+    DF_LANE_TWIDDLES = 1u << 8,  // all 15 pass-0 twiddles of a lane in VGPRs instead of 4 base values + products
+    DF_PSUM_READBACK = 1u << 9,  // power sum by a separate LDS read pass over the staged list (round-1 form)
+};
+
+template <int N, int MOD, int BMODE, int MINW, unsigned FLAGS = 0>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
+    constexpr bool ROT = (FLAGS & DF_ROT) != 0, HG = (FLAGS & DF_HG) != 0, GLDS = (FLAGS & DF_GAINS_GLOBAL) == 0,
+                   NT = (FLAGS & DF_NT) != 0, ASMB = (FLAGS & DF_GENERIC_BITS) == 0, STAMP = (FLAGS & DF_STAMP) != 0,
+                   PIPE = (FLAGS & DF_NO_PIPE) == 0, L2IN = (FLAGS & DF_L2_INPUT) != 0,
+                   CT = (FLAGS & DF_LANE_TWIDDLES) == 0 && Plan<N>::R0 == 16, PSE = (FLAGS & DF_PSUM_READBACK) == 0;
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
     constexpr int T = PL::T, P = PL::P, Q = P / 4, NS = DG::NS;
@@ -532,12 +549,12 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     const int bmode = a.bits ? a.bits_mode : 0;
     if (a.host_guard) {             // tracker receiver: equalised symbols only, frames enabled by the host
         if (bmode != 0 || a.rot) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, true, false, true, false, true, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+        hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, DF_HG>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
         return hipGetLastError();
     }
     if (a.rot) {                    // CFO receiver: equalised symbols only
         if (bmode != 0) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, true, false, true, false, true, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+        hipLaunchKernelGGL((rx_demod_kernel<N, 2, 0, 3, DF_ROT>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
         return hipGetLastError();
     }
 #ifdef OFDM_EXPERIMENTS
@@ -545,19 +562,22 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     // None of them is compiled into the product library; an unknown variant falls through to the shipped kernel.
     if constexpr (N == 2048) {
         if (a.variant != 0 && a.variant < 100 && bmode == 1 && a.mod == 4) {
-            if (a.variant == 1) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 2) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, false, true>), dim3(grid), dim3(DG::WG), DG::lds_bytes(rx.Kd, false), s, rx, a);
-            if (a.variant == 3) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 5) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 6) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 8) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 4, true, false, true, false, true, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 9) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            // 10: round-1 form (lane twiddles in VGPRs, power sum read back from LDS); 11: compact twiddles only; 12: early power sum only
-            if (a.variant == 10) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, false, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 11) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, true, false>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant == 12) hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, 3, true, false, true, false, true, false, false, false, false, true>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
-            if (a.variant >= 10 && a.variant <= 12) return hipGetLastError();
-            if (a.variant >= 1 && a.variant <= 9 && a.variant != 4 && a.variant != 7) return hipGetLastError();
+#define OFDM_LV(V, MW, FL, LDSB)                                                                                            \
+    if (a.variant == V) {                                                                                                   \
+        hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, MW, FL>), dim3(grid), dim3(DG::WG), LDSB, s, rx, a);                   \
+        return hipGetLastError();                                                                                           \
+    }
+            OFDM_LV(1, 3, DF_NT, lds)
+            OFDM_LV(2, 3, DF_GAINS_GLOBAL, DG::lds_bytes(rx.Kd, false))
+            OFDM_LV(3, 3, DF_GENERIC_BITS, lds)
+            OFDM_LV(5, 3, DF_NO_PIPE, lds)
+            OFDM_LV(6, 3, DF_L2_INPUT, lds)
+            OFDM_LV(8, 4, 0u, lds)                                   // 128-VGPR budget
+            OFDM_LV(9, 3, DF_STAMP, lds)
+            OFDM_LV(10, 3, DF_LANE_TWIDDLES | DF_PSUM_READBACK, lds) // the round-1 kernel
+            OFDM_LV(11, 3, DF_PSUM_READBACK, lds)
+            OFDM_LV(12, 3, DF_LANE_TWIDDLES, lds)
+#undef OFDM_LV
         }
     }
 #endif
