@@ -176,6 +176,7 @@ struct ofdm_rx {
     int max_trials = 0;
     int scan_block = 0;                  // > 0: the batch path's sync search is screened in blocks of this many trials
     cf* d_scan_g = nullptr;              // [N + 1] recurrence kernel G
+    int* d_seg_state = nullptr;          // [2] {first hit, segments done} of the stream block's segment-parallel search
     int variant = 0;
     unsigned* d_stamps = nullptr;
     bool profiling = false;
@@ -287,7 +288,7 @@ int ofdm_rx_destroy(ofdm_rx* h) {
     (void)hipSetDevice(h->cfg.device);
     void* ptrs[] = {h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
                     h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime,
-                    h->d_scan_g};
+                    h->d_scan_g, h->d_seg_state};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev)
@@ -436,6 +437,10 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
         int rc2 = dev_alloc(&h->d_scan_g, g.size());
         if (rc2 == OFDM_OK && hipMemcpy(h->d_scan_g, g.data(), g.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess)
             rc2 = fail(OFDM_ERR_HIP, "scan table upload failed");
+        const int seg0[2] = {0x7fffffff, 0};
+        if (rc2 == OFDM_OK) rc2 = dev_alloc(&h->d_seg_state, 2);
+        if (rc2 == OFDM_OK && hipMemcpy(h->d_seg_state, seg0, sizeof seg0, hipMemcpyHostToDevice) != hipSuccess)
+            rc2 = fail(OFDM_ERR_HIP, "segment state upload failed");
         if (rc2 != OFDM_OK) {
             std::string keep = g_last_error;
             ofdm_rx_destroy(h);
@@ -609,6 +614,50 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
             // are evaluated by the reference but can never win, so they are skipped (identical outcome).
             const int64_t need = int64_t(h->tsr[0]) + d.cp + N;            // P*stride > need
             p0 = need >= 0 ? need / d.stride + 1 : 0;
+        }
+        // Screened search (same outcome as trial-by-trial, see rx_sync_scan_kernel): search, accept and finalize in ONE launch
+        // straight into the state rows the accepted trial would get; a miss leaves the state as it was.  The trial range is
+        // searched in parallel segments (a continuing stream finds its next sync ~3 symbols into the buffer, :168).  The row
+        // past the estimate arrays (the reference's IndexError) is left to the path below, which raises it.
+        if (h->scan_block > 0 && p0 < p_valid && p_valid < (int64_t(1) << 30) && h->corr_obs + 1 < h->cfg.num_ofdm_symb) {
+            const int row = h->corr_obs + 1 > 1 ? 1 : h->corr_obs + 1;
+            SyncArgs fa{};
+            fa.iq = h->d_in;
+            fa.frame_stride = n_in;
+            fa.frame_len = n_in;
+            fa.n_frames = 1;
+            fa.mode = 0;
+            fa.p_begin = int(p0);
+            fa.p_count = int(p_valid);
+            fa.keep_on_miss = 1;
+            fa.scan_block = h->scan_block;
+            fa.scan_g = h->d_scan_g;
+            fa.seg_len = h->scan_block;                                                     // one screening block per workgroup
+            fa.n_seg = int((p_valid - p0 + fa.seg_len - 1) / fa.seg_len);
+            fa.seg_state = h->d_seg_state;
+            fa.tsr = h->s_tsr;
+            fa.H = h->s_H + size_t(row) * N;
+            fa.H_for_gain = (row == 0) ? nullptr : h->s_H;                                  // :242 always row 0
+            fa.gain = h->s_gain;
+            fa.htime = h->s_htime + size_t(row) * N;
+            fa.esf = h->s_esf + size_t(row) * d.MM;
+            fa.eqg = h->s_eqg;
+            fa.yscratch = h->s_ysc;
+            HIP_TRY(launch_rx_sync(d, fa, s));
+            int t4[4];
+            HIP_TRY(hipMemcpyAsync(t4, h->s_tsr, sizeof(t4), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (t4[3]) {
+                h->corr_obs += 1;                                                            // :171
+                h->tsr[0] = t4[0];                                                           // :173-175
+                h->tsr[1] = t4[1];
+                h->tsr[2] = t4[2];
+                detected = 1;
+                trials_run = int((int64_t(t4[0]) - d.cp) / d.stride - p0 + 1);
+            } else {
+                trials_run = int(p_valid - p0);
+            }
+            p0 = p_valid;
         }
         int win = 128;
         std::vector<float> tm(ofdm_rx::TRIAL_CAP);

@@ -61,6 +61,11 @@ struct SyncArgs {
     int scan_block;          // mode 0, > 0: screened search (rx_sync_scan_kernel) with blocks of this many trials
     const cf* scan_g;        // [nfft + 1] G[m] = sum_k e^{j 2pi m k/N} conj(zc_k), G[nfft] = G[0]
     unsigned* stamps;        // OFDM_EXPERIMENTS build only: [workgroups][8] cycle sums per phase of the scan kernel, or null
+    int keep_on_miss;        // mode 0: a frame without an accepted trial leaves every output row untouched (stream block: the old
+                             // estimate stays in force, SynchAndChanEst.py:166-219 only writes on detection) except tsr[3] = 0
+    int n_seg;               // screened search of ONE long buffer (n_frames == 1): > 0 = the trials p_begin .. are cut into n_seg
+    int seg_len;             //   segments of seg_len trials searched in parallel; the first accepted trial overall is finalized
+    int* seg_state;          //   [2] device words {first hit so far = INT_MAX, segments done = 0}; the kernel re-arms them
 };
 
 struct DemapArgs {

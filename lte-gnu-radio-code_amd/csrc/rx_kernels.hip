@@ -169,11 +169,14 @@ __device__ __forceinline__ void sync_finalize(const RxDev& rx, const SyncArgs& a
     const int Ks = rx.Ks, Kd = rx.Kd;
     if (active && t == 0) {
         int* o = a.tsr + int64_t(frame) * 4;
-        o[0] = found ? Phit * rx.stride + rx.cp + a.off_delta : 0;                      // :173
-        o[1] = found ? dhats : 0;                                                        // :174
-        o[2] = found ? int(ms) : 0;                                                      // :175
+        if (found || !a.keep_on_miss) {
+            o[0] = found ? Phit * rx.stride + rx.cp + a.off_delta : 0;                  // :173
+            o[1] = found ? dhats : 0;                                                    // :174
+            o[2] = found ? int(ms) : 0;                                                  // :175
+        }
         o[3] = found ? 1 : 0;
     }
+    active = active && (found || !a.keep_on_miss);     // from here on `active` only gates the stores
     // Z (register slot order) -> LDS in natural bin order, then a rolled loop over this lane's bins: the finalize
     // arithmetic runs once per frame, so it is kept small in registers rather than unrolled 16-fold.
 #pragma unroll
@@ -408,7 +411,12 @@ __device__ __forceinline__ void cfma(cf& u, cf d, cf g) {
         : "v"(d), "v"(g));
 }
 
-template <int N, int MINW = 2>
+//
+// SEG (stream block, one long buffer): the trial range is cut into segments of a.seg_len trials, one per workgroup slot, searched in
+// parallel.  Each segment publishes its first accepted trial with an atomicMin; the segment that finishes last re-evaluates the
+// overall minimum exactly (the same code at the same trial: the same numbers) and finalizes it, so the launch still returns
+// the reference's "first accepted trial" and its estimate.  Segments behind an already published hit stop early.
+template <int N, int MINW = 2, bool SEG = false>
 __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev rx, SyncArgs a) {
     using PL = Plan<N>;
     using SG = ScanGeom<N>;
@@ -433,17 +441,23 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     load_twiddles(tw, rx.tw, t);
 
     const int64_t unit = int64_t(blockIdx.x) * SLOTS + slot;
-    const bool active = unit < a.n_frames;
-    const int frame = active ? int(unit) : 0;
+    bool active = unit < (SEG ? a.n_seg : a.n_frames);
+    const int frame = (active && !SEG) ? int(unit) : 0;
     const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
     // (a run-time pointer on purpose: with a literal nullptr hipcc's schedule of the trial needs ~3000 spills at 168 VGPRs)
     cf* ysc = a.yscratch ? a.yscratch + int64_t(frame) * rx.MM : nullptr;
     const int B = a.scan_block, cp = rx.cp;
-    // number of valid trials of this frame: P valid iff S*L + P + N + cp < frame_len (:144), P < p_count
+    // trials p_begin <= P < nvalid are searched: P valid iff S*L + P + N + cp < frame_len (:144), P < p_count
     int64_t nvalid64 = a.frame_len - (int64_t(rx.S) * rx.L + N + cp);
     if (nvalid64 < 0) nvalid64 = 0;
     if (a.p_count > 0 && nvalid64 > a.p_count) nvalid64 = a.p_count;
-    const int nvalid = active ? int(nvalid64 < (1 << 30) ? nvalid64 : (1 << 30)) : 0;
+    int nvalid = active ? int(nvalid64 < (1 << 30) ? nvalid64 : (1 << 30)) : 0;
+    int P0 = a.p_begin;
+    if constexpr (SEG) {
+        const int64_t first = int64_t(a.p_begin) + (active ? unit : 0) * a.seg_len;
+        P0 = int(first < (1 << 30) ? first : (1 << 30));
+        if (int64_t(nvalid) > first + a.seg_len) nvalid = int(first + a.seg_len);
+    }
 
     // the table G[1 .. B + cp] -> LDS once; entries -BMAX .. 0 are ZERO: alignments behind the current trial add nothing, branch-free
     for (int i = t - SG::BMAX; i <= QM * T; i += T) Gl[i] = i > 0 ? a.scan_g[i] : cf{0.f, 0.f};
@@ -477,9 +491,13 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
 #else
 #define SCAN_STAMP(i) do { } while (0)
 #endif
-    int P0 = 0;
+    for (int pass = 0;; ++pass) {
     for (;;) {
-        const bool blk_on = !found && P0 < nvalid;
+        bool blk_on = !found && P0 < nvalid;
+        if constexpr (SEG) {
+            // a hit published by an earlier segment ends this one: nothing at or after P0 can be the first accepted trial
+            if (pass == 0 && __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P0) blk_on = false;
+        }
         if (!__syncthreads_or(blk_on ? 1 : 0)) break;
         SCAN_STAMP(0);
         // ---- (1) anchor: exact trial at P0
@@ -682,6 +700,35 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         // the first flagged trial is the next anchor (evaluated exactly there); an unflagged block is skipped whole
         if (nb > 0) P0 += (cand < nb) ? cand : nb;
         SCAN_STAMP(5);                                                       // .. candidate reduction
+    }
+    if (!SEG || pass == 1) break;
+    if constexpr (SEG) {
+        // publish, take a ticket; the slot holding the last ticket goes round once more with the winning trial as its only one
+        wg_barrier();
+        if (t == 0) {
+            int last = 0;
+            if (active) {
+                if (found) atomicMin(a.seg_state, Phit);
+                __threadfence();
+                last = atomicAdd(a.seg_state + 1, 1) == a.n_seg - 1;
+            }
+            int win = 0x7fffffff;
+            if (last) {
+                __threadfence();
+                win = atomicExch(a.seg_state, 0x7fffffff);               // read the minimum and re-arm both words for the next launch
+                atomicExch(a.seg_state + 1, 0);
+            }
+            cflag[0] = last ? win : -1;                                  // -1: this slot is not the last one
+        }
+        wg_barrier();
+        const int win = cflag[0];
+        wg_barrier();
+        if (!__syncthreads_or(win >= 0 ? 1 : 0)) return;                // no slot of this workgroup holds the last ticket
+        active = win >= 0;
+        found = false;
+        P0 = (active && win != 0x7fffffff) ? win : 0;
+        nvalid = (active && win != 0x7fffffff) ? win + 1 : 0;
+    }
     }
     SCAN_STAMP(6);
     sync_finalize<N>(rx, a, frame, active, found, Phit, Zs, zdups, pests, ms, dhats, lds, tw, w1tab, t, ysc);
@@ -904,10 +951,16 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
     if (grid == 0) return hipSuccess;
     if (a.mode == 0 && a.scan_block > 0) {
         if (a.scan_block != scan_block_n<N>(rx) || !a.scan_g || a.rot || a.force_accept || a.host_valid || a.off_delta || a.force_dhat_p1 ||
-            a.p_begin != 0)
+            a.p_begin < 0)
             return hipErrorInvalidValue;
         // register budget: 168 VGPRs (3 waves per SIMD) costs ~23 spills for one frame per workgroup (N >= 1024); the packed small
         // sizes keep a second copy of Z and get 256
+        if (a.n_seg > 0) {
+            if (a.n_frames != 1 || a.seg_len <= 0 || !a.seg_state) return hipErrorInvalidValue;
+            const unsigned gseg = unsigned((int64_t(a.n_seg) + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+            hipLaunchKernelGGL((rx_sync_scan_kernel<N, 2, true>), dim3(gseg), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((rx_sync_scan_kernel<N, 2>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
         return hipGetLastError();
     }

@@ -129,3 +129,50 @@ def test_screen_is_off_where_its_preconditions_fail(om):
     assert om.RxEngine(10, 64, 16, 62, (2, 3), 60, 100).set_sync_search(False) is False         # two sync symbols per pattern
     assert om.RxEngine(8, 64, 16, 62, (1, 3), 60, 100, compat=om.COMPAT_RXOFDM).set_sync_search(False) is False   # stride cp-1
     assert om.RxEngine(8, 64, 60, 62, (1, 3), 60, 100).set_sync_search(False) is False          # cp too long for one block
+
+
+@pytest.mark.parametrize("N,cp,Kd,n_sym", [(64, 16, 60, 12), (256, 18, 152, 12), (2048, 144, 1200, 12)])
+def test_stream_block_uses_the_screened_search_with_the_same_outcome(om, N, cp, Kd, n_sym):
+    """`work()` on host buffers (the GNU Radio path) searches, accepts and finalizes in one launch.  A sequence of calls -- sync
+    deep in the buffer, at sample 0, a buffer of noise only (nothing found: the previous estimate must stay), then a late sync
+    again -- must leave the same report, output items and state rows as the exhaustive search and as the oracle."""
+    L = N + cp
+    leads = [L + 7, 0, None, 3 * L - 1, 17]
+    rng = np.random.default_rng(N + 1)
+    bufs = []
+    for ld in leads:
+        if ld is None:
+            fl = n_sym * L
+            bufs.append((0.2 * (rng.standard_normal(fl) + 1j * rng.standard_normal(fl))).astype(np.complex64))
+        else:
+            _, iq = _frames_with_leads(N, cp, Kd, n_sym, [ld], 0.02, seed=int(rng.integers(1 << 30)))
+            bufs.append(iq[0][:n_sym * L].copy())
+    scr = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+    exh = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+    assert scr.set_sync_search(False) is True and exh.set_sync_search(True) is False
+    o = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 100, 0.7, force_fp64=True)
+    n_det = 0
+    for i, x in enumerate(bufs):
+        out_s, out_x, out_o = (np.zeros(len(x), np.complex64) for _ in range(3))
+        n_s, n_x = scr.work(x, out_s), exh.work(x, out_x)
+        n_o = o.work(x, out_o)
+        rs, rx_ = scr.report, exh.report
+        assert n_s == n_x == n_o, (i, n_s, n_x, n_o)
+        for fld in ("detected", "trials_run", "count", "corr_obs", "n_data_items"):
+            assert getattr(rs, fld) == getattr(rx_, fld), (i, fld)
+        assert list(rs.time_synch_ref) == list(rx_.time_synch_ref), i
+        assert rs.time_synch_ref[0] == o.time_synch_ref[0] and rs.time_synch_ref[1] == o.time_synch_ref[1], i
+        assert rs.corr_obs == o.corr_obs, i
+        n_det += rs.detected
+        if leads[i] is None:
+            assert not rs.detected
+        if n_s > 0:
+            ok = np.isfinite(out_o[:n_s]) & np.isfinite(out_s[:n_s])
+            assert np.array_equal(np.isfinite(out_s[:n_s]), np.isfinite(out_x[:n_s]))
+            assert relerr(out_s[:n_s][ok], out_x[:n_s][ok]) < 2e-6
+            assert_close(out_s[:n_s][ok], out_o[:n_s][ok], "call %d" % i)
+        for row in (0, 1):
+            a, b = scr.state(row), exh.state(row)
+            for k in ("chan_freq", "chan_time", "synch_freq", "eq_gain"):
+                assert relerr(a[k], b[k]) < 2e-6, (i, row, k)
+    assert n_det >= 3

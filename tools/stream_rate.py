@@ -24,14 +24,11 @@ for _ in range(n):
     blk.work([iq], [out])
 dt = (time.perf_counter() - t0) / n
 print("stream block work(): %.3f ms per %d-sample buffer -> %.1f Msamples/s (H2D + sync search + demod + D2H + host packing)" % (dt * 1e3, len(iq), len(iq) / dt / 1e6))
-for chunk in (8192, 65536):
+for rows in (4, 32):                      # GNU Radio sized buffers: whole [S, D] patterns (anything else raises the reference's ValueError)
+    chunk = rows * L
     b = iq[:chunk]; o = np.zeros(chunk, np.complex64)
-    nrows = chunk // L; nrows += (-nrows) % 4
-    try:
-        blk2 = utsa_ofdm.SynchAndChanEst(max(4, nrows), N, cp, N - 2, [1, 3], Kd, 100, 0.7, "/tmp/", "x", 0, 0)
-        blk2.work([b], [o]); t0 = time.perf_counter()
-        for _ in range(20): blk2.work([b], [o])
-        dt = (time.perf_counter() - t0) / 20
-        print("  %6d-sample buffers: %.3f ms -> %.1f Msamples/s" % (chunk, dt * 1e3, chunk / dt / 1e6))
-    except Exception as e:
-        print("  %6d-sample buffers: %s: %s" % (chunk, type(e).__name__, e))
+    blk2 = utsa_ofdm.SynchAndChanEst(rows, N, cp, N - 2, [1, 3], Kd, 100, 0.7, "/tmp/", "x", 0, 0)
+    blk2.work([b], [o]); t0 = time.perf_counter()
+    for _ in range(20): blk2.work([b], [o])
+    dt = (time.perf_counter() - t0) / 20
+    print("  %6d-sample buffers (%d symbols): %.3f ms -> %.1f Msamples/s" % (chunk, rows, dt * 1e3, chunk / dt / 1e6))
