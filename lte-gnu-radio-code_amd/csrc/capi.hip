@@ -1586,6 +1586,7 @@ int ofdm_tx_modulate_frames(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode
     const int64_t bits_per_frame = n_data * d.Kd * d.bps;
     if (bits_mode == OFDM_BITS_PACKED && (bits_per_frame & 7))
         return fail(OFDM_ERR_INVALID, "packed bits need a whole number of bytes per frame");
+    if (bits_per_frame > INT32_MAX) return fail(OFDM_ERR_INVALID, "more than 2^31 bits per frame");
     HIP_TRY(hipSetDevice(h->cfg.device));
     ModArgs a{};
     a.bits = d_bits;

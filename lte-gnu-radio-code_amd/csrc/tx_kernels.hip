@@ -5,6 +5,7 @@
 //                       (reference: LEGACY/gr-ofdm-rx/python/txrx_mod/MultiAntennaSystem.py:113-218,
 //                        SynchSignal.py:13-30)
 //   channel_kernel      tapped-delay-line convolution + Philox/Box-Muller AWGN  (MultiAntennaSystem.py:221-260)
+#include <cstdlib>
 #include "ofdm_launch.hpp"
 
 namespace ofdm {
@@ -43,6 +44,87 @@ __device__ __forceinline__ unsigned read_bits(const uint8_t* bits, int mode, int
         }
     }
     return v;
+}
+
+// ---- the bit words of one lane's P bins.  KIND is compile-time: 2 / 4 / 6 = bits per constellation symbol of a one-bit-per-
+// byte stream whose frames start 4-byte aligned (one or three wide loads per bin, ALL issued before the first is used: loads
+// behind per-bin branches go out one at a time, each waiting for the one before -- 16 memory latencies per symbol);
+// 10 / 12 / 14 = 8 + bits per symbol of a packed stream (8 bits per byte, MSB first: one or two byte loads per bin);
+// 0 = anything else (BPSK, unaligned one-bit-per-byte streams), read bit by bit.
+// Bin q reads constellation symbol base + li[q] of the frame's stream (li < 0: unused bin -> entry `base`, masked by the caller);
+// 32-bit symbol numbers: a frame's stream is < 2^31 bits (checked by the host).
+#define OFDM_KEEP16(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), \
+                                         "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]))
+#define OFDM_KEEP8(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]))
+template <int P>
+__device__ __forceinline__ void keep_loads(unsigned (&r)[P]) {
+    static_assert(P == 16 || P == 8, "lane bins");
+    if constexpr (P == 16) OFDM_KEEP16(r); else OFDM_KEEP8(r);
+}
+
+template <int P, int KIND>
+struct TxFetch {
+    unsigned w[KIND == 6 ? 3 : (KIND == 14 ? 2 : 1)][P];
+};
+__host__ __device__ __forceinline__ int tx_fetch_kind(int mode, int bps, bool al4) {
+    if (bps != 2 && bps != 4 && bps != 6) return 0;
+    if (mode == 2) return al4 ? bps : 0;
+    return 8 + bps;
+}
+template <int P, int KIND>
+__device__ __forceinline__ void tx_fetch_issue(const uint8_t* bits, unsigned base, const int (&li)[P], TxFetch<P, KIND>& f) {
+    if constexpr (KIND == 4) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) f.w[0][q] = *reinterpret_cast<const uint32_t*>(bits + (base + max(li[q], 0)) * 4u);
+    } else if constexpr (KIND == 2) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) f.w[0][q] = *reinterpret_cast<const uint16_t*>(bits + (base + max(li[q], 0)) * 2u);
+    } else if constexpr (KIND == 6) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const uint16_t* p = reinterpret_cast<const uint16_t*>(bits + (base + max(li[q], 0)) * 6u);
+            f.w[0][q] = p[0];
+            f.w[1][q] = p[1];
+            f.w[2][q] = p[2];
+        }
+    } else if constexpr (KIND == 12 || KIND == 10) {
+        constexpr unsigned sh = KIND == 12 ? 1u : 2u;                       // symbols per byte = 1 << sh
+#pragma unroll
+        for (int q = 0; q < P; ++q) f.w[0][q] = bits[(base + max(li[q], 0)) >> sh];
+    } else if constexpr (KIND == 14) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const unsigned b0 = (base + max(li[q], 0)) * 6u;
+            f.w[0][q] = bits[b0 >> 3];
+            f.w[1][q] = bits[(b0 >> 3) + ((b0 & 7u) > 2u ? 1u : 0u)];      // the second byte only where the symbol reaches into it
+        }
+    }
+    // one empty asm with every result as an operand: the loads above are all issued before the first of them is used
+    if constexpr (KIND != 0) keep_loads(f.w[0]);
+    if constexpr (KIND == 6 || KIND == 14) keep_loads(f.w[1]);
+    if constexpr (KIND == 6) keep_loads(f.w[2]);
+}
+// the bps-bit value, MSB first
+template <int P, int KIND>
+__device__ __forceinline__ unsigned tx_fetch_value(const uint8_t* bits, int mode, int bps, unsigned base, int li, const TxFetch<P, KIND>& f,
+                                                   int q) {
+    if constexpr (KIND == 4) {
+        const uint32_t w = f.w[0][q];
+        return ((w & 1u) << 3) | ((w >> 6) & 4u) | ((w >> 15) & 2u) | ((w >> 24) & 1u);
+    } else if constexpr (KIND == 2) {
+        return ((f.w[0][q] & 1u) << 1) | ((f.w[0][q] >> 8) & 1u);
+    } else if constexpr (KIND == 6) {
+        return ((f.w[0][q] & 1u) << 5) | (((f.w[0][q] >> 8) & 1u) << 4) | ((f.w[1][q] & 1u) << 3) | (((f.w[1][q] >> 8) & 1u) << 2) |
+               ((f.w[2][q] & 1u) << 1) | ((f.w[2][q] >> 8) & 1u);
+    } else if constexpr (KIND == 12) {
+        return (f.w[0][q] >> (4u - ((base + max(li, 0)) & 1u) * 4u)) & 15u;
+    } else if constexpr (KIND == 10) {
+        return (f.w[0][q] >> (6u - ((base + max(li, 0)) & 3u) * 2u)) & 3u;
+    } else if constexpr (KIND == 14) {
+        return (((f.w[0][q] << 8) | f.w[1][q]) >> (10u - (((base + max(li, 0)) * 6u) & 7u))) & 63u;
+    } else {
+        return read_bits(bits, mode, int64_t(base + max(li, 0)) * bps, bps);
+    }
 }
 
 // MultiAntennaSystem.py:156-178 (BPSK, QPSK); 16/64-QAM: 3GPP TS 36.211 7.1 (extension)
@@ -92,9 +174,9 @@ __device__ __forceinline__ void tx_time_from_fft(cf (&v)[Plan<N>::P]) {
 
 // x (register slot order: sample m = (t + T*j) + NC*kl in x[out_slot(j,kl)]) -> CP-extended, power-normalised symbol at `o`
 // (:200-218): energy and mean over the CP-extended symbol in one pass (CP samples count twice), then one scale.
+// Two halves, so that the fused kernel can issue the next symbol's loads between them (ahead of this symbol's stores).
 template <int N>
-__device__ __forceinline__ void tx_cp_norm_store(const TxDev& tx, const cf (&x)[Plan<N>::P], cf* lds, float* red, int t, cf* o,
-                                                 bool active) {
+__device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)[Plan<N>::P], cf* lds, float* red, int t) {
     using PL = Plan<N>;
     constexpr int T = PL::T;
     float e = 0.f, sx = 0.f, sy = 0.f;
@@ -111,28 +193,77 @@ __device__ __forceinline__ void tx_cp_norm_store(const TxDev& tx, const cf (&x)[
             sy += w * xv.y;
         }
     }
-    e = symbol_sum<T>(e, red, t);
-    if constexpr (T > 64) wg_barrier();
-    sx = symbol_sum<T>(sx, red, t);
-    if constexpr (T > 64) wg_barrier();
-    sy = symbol_sum<T>(sy, red, t);
+    // the three sums share one exchange (and the barrier that publishes the staged samples)
+    e = lanes_sum<T>(e);
+    sx = lanes_sum<T>(sx);
+    sy = lanes_sum<T>(sy);
+    if constexpr (T > 64) {
+        if ((t & 63) == 0) {
+            float* r3 = red + (t >> 6) * 3;
+            r3[0] = e;
+            r3[1] = sx;
+            r3[2] = sy;
+        }
+    }
     wg_barrier();
+    if constexpr (T > 64) {
+        e = sx = sy = 0.f;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) {
+            e += red[w * 3];
+            sx += red[w * 3 + 1];
+            sy += red[w * 3 + 2];
+        }
+    }
     const float Lf = float(tx.L);
     const float a1 = (e > 1e-30f) ? sqrtf(Lf / e) : 1.f;              // :204-205
     const float mx = a1 * sx / Lf, my = a1 * sy / Lf;
     const float var = a1 * a1 * e / Lf - (mx * mx + my * my);         // np.var(data_time) :213
-    const float scale = a1 / sqrtf(var);                              // :218
+    return a1 / sqrtf(var);                                           // :218
+}
+
+template <int N>
+__device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, float scale, int t, cf* o, bool active) {
+    constexpr int T = Plan<N>::T;
     if (active) {
-        for (int j = t; j < tx.L; j += T) {
-            int m = j - tx.cp;
-            if (m < 0) m += N;
-            o[j] = cscale(lds[m], scale);
+        // sample j of the symbol is x[(j - cp) mod N]; with cp and L even a pair (j, j+1) never straddles the wrap: 16 B per lane
+        if (((tx.cp | tx.L) & 1) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+            const float4* l4 = reinterpret_cast<const float4*>(lds);
+            float4* o4 = reinterpret_cast<float4*>(o);
+            const int h = tx.cp >> 1, half = tx.L >> 1;
+            for (int j0 = t; j0 < half; j0 += 4 * T) {
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                              // four reads in flight, then four stores
+                    int m = min(j0 + u * T, half - 1) - h;
+                    if (m < 0) m += N / 2;
+                    q[u] = l4[m];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * T;
+                    q[u].x *= scale;
+                    q[u].y *= scale;
+                    q[u].z *= scale;
+                    q[u].w *= scale;
+                    if (j < half) o4[j] = q[u];
+                }
+            }
+        } else {
+            for (int j = t; j < tx.L; j += T) {
+                int m = j - tx.cp;
+                if (m < 0) m += N;
+                o[j] = cscale(lds[m], scale);
+            }
         }
     }
 }
 
-template <int N>
-__global__ void __launch_bounds__(Plan<N>::WG) tx_modulate_kernel(TxDev tx, ModArgs a) {
+// One workgroup slot walks symbols unit, unit + stride, ...: twiddles and the pass-1 table are set up once per workgroup.
+// (Requesting the next symbol's bit words ahead of this symbol's stores -- the software pipeline of the receive kernel -- was
+// measured and bought nothing here: the kernel is VALU-issue-bound at 4 waves per SIMD, not waiting for memory.)
+template <int N, int KIND>
+__global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, ModArgs a) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -144,41 +275,79 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_modulate_kernel(TxDev tx, ModA
     float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
     const cf* w1tab = wg_init_w1<N>(smem, tx.tw, tid);
 
-    LaneTwiddles<N> tw;
-    load_twiddles<N>(tw, tx.tw, t);
+    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, tx.tw, t);
 
-    const int64_t unit = int64_t(blockIdx.x) * PL::SLOTS + slot;
-    const bool active = unit < int64_t(a.n_frames) * a.n_sym;
-    const int frame = active ? int(unit / a.n_sym) : 0;
-    const int sym = active ? int(unit % a.n_sym) : 0;
     const int SD = tx.S + tx.D;
-    const int pat = sym / SD, r = sym - pat * SD;
-    const bool is_sync = r < tx.S;                                    // symbol_pattern == 0  (:136)
-    const int64_t ds = int64_t(pat) * tx.D + (r - tx.S);              // loop_data (:134,180)
-    const uint8_t* fbits = a.bits ? a.bits + int64_t(frame) * a.bits_stride : nullptr;
-
-    // resource grid row X[n] (:135-183), conjugated: ifft(X) = conj(fft(conj(X))) / N
-    cf v[P];
-#pragma unroll
-    for (int n0 = 0; n0 < P; ++n0) {
-        const int n = t + T * n0;
-        cf X = cf{0.f, 0.f};
-        int i;
-        if (active) {
-            if (is_sync) {
-                // x_in = zchu[0:Ks] on used_bins_synch; synch_state never advances (:143-147)
-                if (data_bin_index(n, tx.Ks, N, i)) X = tx.zc[i];     // a bin listed twice keeps the later entry
-            } else if (fbits) {
-                if (data_bin_index(n, tx.Kd, N, i)) X = map_symbol(read_bits(fbits, a.bits_mode, (ds * tx.Kd + i) * tx.bps, tx.bps), tx.bps);
-            }
+    const int64_t n_units = int64_t(a.n_frames) * a.n_sym;
+    // trip count of the workgroup's first slot: workgroup-uniform, so the loop needs no vote (and no wait for its stores)
+    const int64_t stride = int64_t(gridDim.x) * PL::SLOTS, first = int64_t(blockIdx.x) * PL::SLOTS;
+    const int n_iter = first < n_units ? int((n_units - first + stride - 1) / stride) : 0;
+    // (frame, symbol) of the slot's unit, advanced by the stride without a division per symbol
+    const int64_t unit0 = first + slot;
+    int frame_u = int(unit0 / a.n_sym), sym_u = int(unit0 % a.n_sym);
+    const int step_f = int(stride / a.n_sym), step_s = int(stride % a.n_sym);
+    for (int it = 0; it < n_iter; ++it) {
+        const bool active = unit0 + int64_t(it) * stride < n_units;
+        const int frame = active ? frame_u : 0;
+        const int sym = active ? sym_u : 0;
+        frame_u += step_f;
+        sym_u += step_s;
+        if (sym_u >= a.n_sym) {
+            sym_u -= a.n_sym;
+            ++frame_u;
         }
-        v[n0] = cconj(X);
+        const int pat = sym / SD, r = sym - pat * SD;
+        const bool is_sync = r < tx.S;                                    // symbol_pattern == 0  (:136)
+        const unsigned base = unsigned(pat * tx.D + (r - tx.S)) * unsigned(tx.Kd);   // loop_data (:134,180) * Kd
+        const uint8_t* fbits = a.bits ? a.bits + int64_t(frame) * a.bits_stride : nullptr;
+
+        // resource grid row X[n] (:135-183), conjugated: ifft(X) = conj(fft(conj(X))) / N.
+        // list index of bin n in binsP(K), -1 = unused.  The lane's bin numbers go through an opaque copy of t: hoisted out of
+        // the symbol loop, the 16 list indices and addresses cost ~100 VGPRs and the occupancy with them.
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        int li[P];
+#pragma unroll
+        for (int n0 = 0; n0 < P; ++n0) {
+            int i;
+            const bool has = data_bin_index(tt + T * n0, is_sync ? tx.Ks : tx.Kd, N, i);     // a bin listed twice keeps the later entry
+            li[n0] = (has && active) ? i : -1;
+        }
+        cf v[P];
+        if (is_sync) {
+            // x_in = zchu[0:Ks] on used_bins_synch; synch_state never advances (:143-147).  All entries requested together.
+            unsigned zr[P], zi[P];
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) {
+                const cf z = tx.zc[max(li[n0], 0)];
+                zr[n0] = __float_as_uint(z.x);
+                zi[n0] = __float_as_uint(z.y);
+            }
+            keep_loads(zr);
+            keep_loads(zi);
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0)
+                v[n0] = li[n0] < 0 ? cf{0.f, 0.f} : cf{__uint_as_float(zr[n0]), -__uint_as_float(zi[n0])};
+        } else if (fbits) {
+            TxFetch<P, KIND> f;
+            tx_fetch_issue<P, KIND>(fbits, base, li, f);
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) {
+                const unsigned val = tx_fetch_value<P, KIND>(fbits, a.bits_mode, tx.bps, base, li[n0], f, n0);
+                v[n0] = li[n0] < 0 ? cf{0.f, 0.f} : cconj(map_symbol(val, KIND != 0 ? (KIND & 7) : tx.bps));
+            }
+        } else {
+#pragma unroll
+            for (int n0 = 0; n0 < P; ++n0) v[n0] = cf{0.f, 0.f};
+        }
+        wg_fft<N>(v, lds, tw, w1tab, t);                                         // :199
+        wg_barrier();
+        tx_time_from_fft<N>(v);
+        const float scale = tx_cp_norm_stage<N>(tx, v, lds, red, t);
+        tx_cp_store<N>(tx, lds, scale, t, a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L, active);
+        wg_barrier();                                                            // the staged symbol has been read by every lane
     }
-    wg_fft<N>(v, lds, tw, w1tab, t);                                         // :199
-    wg_barrier();
-    tx_time_from_fft<N>(v);
-    cf* o = a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L;
-    tx_cp_norm_store<N>(tx, v, lds, red, t, o, active);
 }
 
 // ------------------------------------------------------------------------------------------ decomposed stages
@@ -259,7 +428,7 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_time_kernel(TxDev tx, TimeArgs
     const cf* in = a.in + (active ? row : 0) * N;
     cf v[P];
     if constexpr (DO_IFFT) {
-        LaneTwiddles<N> tw;
+        std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;      // as the fused kernel: same numbers
         load_twiddles<N>(tw, tx.tw, t);
 #pragma unroll
         for (int n0 = 0; n0 < P; ++n0) v[n0] = active ? cconj(in[t + T * n0]) : cf{0.f, 0.f};
@@ -275,7 +444,8 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_time_kernel(TxDev tx, TimeArgs
         }
     }
     if constexpr (DO_CP) {
-        tx_cp_norm_store<N>(tx, v, lds, red, t, a.out + (active ? row : 0) * tx.L, active);
+        const float scale = tx_cp_norm_stage<N>(tx, v, lds, red, t);
+        tx_cp_store<N>(tx, lds, scale, t, a.out + (active ? row : 0) * tx.L, active);
     } else {
         if (active) {
 #pragma unroll
@@ -375,9 +545,20 @@ hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sy
 template <int N>
 static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s) {
     const int64_t units = int64_t(a.n_frames) * a.n_sym;
-    const unsigned grid = unsigned((units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    const int64_t wgs = (units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS;
+    const unsigned grid = unsigned(std::min<int64_t>(wgs, 256 * 8));      // 8 resident workgroups per CU; the rest is looped
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(tx_modulate_kernel<N>, dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, tx, a);
+    const bool al4 = a.bits && ((reinterpret_cast<uintptr_t>(a.bits) | uintptr_t(a.bits_stride)) & 3) == 0;
+    const dim3 g(grid), b(Plan<N>::WG);
+    switch (tx_fetch_kind(a.bits_mode, tx.bps, al4)) {
+        case 2: hipLaunchKernelGGL((tx_modulate_kernel<N, 2>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+        case 4: hipLaunchKernelGGL((tx_modulate_kernel<N, 4>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+        case 6: hipLaunchKernelGGL((tx_modulate_kernel<N, 6>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+        case 10: hipLaunchKernelGGL((tx_modulate_kernel<N, 10>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+        case 12: hipLaunchKernelGGL((tx_modulate_kernel<N, 12>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+        case 14: hipLaunchKernelGGL((tx_modulate_kernel<N, 14>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+        default: hipLaunchKernelGGL((tx_modulate_kernel<N, 0>), g, b, WgLds<N>::BYTES, s, tx, a); break;
+    }
     return hipGetLastError();
 }
 
