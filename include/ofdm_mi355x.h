@@ -124,11 +124,13 @@ int ofdm_rx_get_kernel_ms(ofdm_rx* h, float* sync_ms, float* demod_ms);
  * reference, :143).  A frame with no sync costs one FFT pair per sample, so hosts may cap it. */
 int ofdm_rx_set_max_trials(ofdm_rx* h, int32_t max_trials);
 
-/* Sync search of the batch path.  The reference tries the windows P = 0, 1, 2, ... one by one (:143-169); exhaustive != 0 does
- * exactly that, one workgroup per frame.  exhaustive == 0 (default) uses the screened search where its preconditions hold
+/* Sync search of the batch path and of ofdm_rx_work.  The reference tries the windows P = 0, 1, 2, ... one by one (:143-169);
+ * exhaustive != 0 does exactly that (batch: one workgroup per frame; ofdm_rx_work: a trial table in windows, then a finalize
+ * launch).  exhaustive == 0 (default) uses the screened search where its preconditions hold
  * (synch_dat[0] == 1, stride 1, num_synch_bins == nfft - 2): the trials between exactly evaluated anchor trials are screened
  * with an O(cp) sliding recurrence of the lag correlations and only flagged trials are evaluated exactly -- the accepted trial,
- * its lag and every output are those of the exhaustive search.  Returns 1 if the screened search is
+ * its lag and every output are those of the exhaustive search; ofdm_rx_work then searches its one
+ * buffer in parallel segments and accepts and finalizes the first hit in the same launch.  Returns 1 if the screened search is
  * active for this handle afterwards, 0 if the exhaustive one is, or a negative ofdm_status. */
 int ofdm_rx_set_sync_search(ofdm_rx* h, int32_t exhaustive);
 
