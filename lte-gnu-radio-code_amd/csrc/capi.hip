@@ -90,8 +90,13 @@ std::vector<cf> make_scan_table(int N, int Ks, const std::vector<cf>& zc) {
                 g[size_t(i + k + len / 2)] = x - y;
             }
     }
-    std::vector<cf> out(size_t(N) + 1);
-    for (int m = 0; m <= N; ++m) out[size_t(m)] = cf{float(g[size_t(m % N)].real()), float(g[size_t(m % N)].imag())};
+    std::vector<cf> out(size_t(N) + 2);
+    double gmax = 0.0;
+    for (int m = 0; m <= N; ++m) {
+        out[size_t(m)] = cf{float(g[size_t(m % N)].real()), float(g[size_t(m % N)].imag())};
+        gmax = std::max(gmax, std::abs(g[size_t(m % N)]));
+    }
+    out[size_t(N) + 1] = cf{float(gmax * (1.0 + 1e-6)), 0.f};          // max |G[m]|: the checkpoint bound of the screened search
     return out;
 }
 
@@ -175,7 +180,7 @@ struct ofdm_rx {
     cf* f_htime = nullptr;
     int max_trials = 0;
     int scan_block = 0;                  // > 0: the batch path's sync search is screened in blocks of this many trials
-    cf* d_scan_g = nullptr;              // [N + 1] recurrence kernel G
+    cf* d_scan_g = nullptr;              // [N + 2] recurrence kernel G, then {max |G|, 0}
     int* d_seg_state = nullptr;          // [2] {first hit, segments done} of the stream block's segment-parallel search
     int variant = 0;
     unsigned* d_stamps = nullptr;

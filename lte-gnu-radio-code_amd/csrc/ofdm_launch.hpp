@@ -59,7 +59,7 @@ struct SyncArgs {
     int gain_lag;
     int force_dhat_p1;       // mode 0: lag+1 that replaces the trial's own arg-max lag (SynchEstAndFO.py:285,300); 0 = off
     int scan_block;          // mode 0, > 0: screened search (rx_sync_scan_kernel) with blocks of this many trials
-    const cf* scan_g;        // [nfft + 1] G[m] = sum_k e^{j 2pi m k/N} conj(zc_k), G[nfft] = G[0]
+    const cf* scan_g;        // [nfft + 2] G[m] = sum_k e^{j 2pi m k/N} conj(zc_k), G[nfft] = G[0], then {max |G|, 0}
     unsigned* stamps;        // OFDM_EXPERIMENTS build only: [workgroups][8] cycle sums per phase of the scan kernel, or null
     int keep_on_miss;        // mode 0: a frame without an accepted trial leaves every output row untouched (stream block: the old
                              // estimate stays in force, SynchAndChanEst.py:166-219 only writes on detection) except tsr[3] = 0

@@ -399,7 +399,10 @@ struct ScanGeom {
     static constexpr int DL_OFF = 0, XN_OFF = BMAX + 2 * UNR, GZ_OFF = XN_OFF + BMAX, G_OFF = GZ_OFF + BMAX,
                          THR_OFF = G_OFF + QM * T + 2;
     static constexpr int FLAG_OFF = THR_OFF + (BMAX + 2 * UNR + 1) / 2;
-    static constexpr int EXTRA = FLAG_OFF + 1;
+    static constexpr int CK = 16;                                     // steps per checkpoint window (a multiple of 2 UNR)
+    static constexpr int NCHK = BMAX / CK + 2;
+    static constexpr int CHK_OFF = FLAG_OFF + 1;                      // tchk[NCHK floats]
+    static constexpr int EXTRA = CHK_OFF + (NCHK + 1) / 2;
     static constexpr size_t BYTES = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * EXTRA * sizeof(cf);
 };
 
@@ -436,6 +439,8 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     cf* Gl = extra + SG::G_OFF;           // preceded by BMAX zero entries: alignments that are not needed yet add nothing
     float* thr = reinterpret_cast<float*>(extra + SG::THR_OFF);
     int* cflag = reinterpret_cast<int*>(extra + SG::FLAG_OFF);
+    float* tchk = reinterpret_cast<float*>(extra + SG::CHK_OFF);
+    const float gmax = a.scan_g[N + 1].x * (1.f + 1e-5f);             // max |G[m]| (host, fp64), rounded up
 
     std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
     load_twiddles(tw, rx.tw, t);
@@ -628,6 +633,41 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             }
             if (t == 0) *cflag = 0x7fffffff;
             wg_barrier();
+            // Checkpoints.  Window c = steps c CK + 1 .. (c+1) CK.  One step changes a correlation value by D_j G[.], at most
+            // |D_j| max|G|, so no value can pass its threshold inside the window unless it starts the window within
+            // sum |D| max|G| of the window's lowest threshold: |u|^2 > tchk[c] = (sqrt(min thr) - sum|D| max|G|)^2 is tested
+            // once per window and only windows that pass it run the per-step tests (tchk < 0: always).
+            if constexpr (T >= SG::CK) {
+                // one (threshold, |D|) entry per lane, reduced over the CK lanes of a window
+                for (int e0 = 0; e0 < SG::NCHK * SG::CK; e0 += T) {
+                    const int e = e0 + t;
+                    const bool in = e + 1 < SG::BMAX + 2 * SG::UNR;
+                    float lo = in ? thr[e + 1] : 3.0e38f;
+                    float dsum = in ? sqrtf(cnorm2(xo[e])) : 0.f;
+#pragma unroll
+                    for (int m = SG::CK >> 1; m >= 1; m >>= 1) {
+                        lo = fminf(lo, __shfl_xor(lo, m, SG::CK));
+                        dsum += __shfl_xor(dsum, m, SG::CK);
+                    }
+                    const float s_ = sqrtf(fmaxf(lo, 0.f)) - dsum * gmax;
+                    if ((e & (SG::CK - 1)) == 0 && e < SG::NCHK * SG::CK) tchk[e / SG::CK] = (lo > 0.f && s_ > 0.f) ? s_ * s_ : -1.f;
+                }
+            } else {
+                for (int c = t; c < SG::NCHK; c += T) {
+                    float lo = 3.0e38f, dsum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < SG::CK; ++i) {
+                        const int j = c * SG::CK + 1 + i;
+                        if (j < SG::BMAX + 2 * SG::UNR) {
+                            lo = fminf(lo, thr[j]);
+                            dsum += sqrtf(cnorm2(xo[j - 1]));
+                        }
+                    }
+                    const float s_ = sqrtf(fmaxf(lo, 0.f)) - dsum * gmax;
+                    tchk[c] = (lo > 0.f && s_ > 0.f) ? s_ * s_ : -1.f;
+                }
+            }
+            wg_barrier();
             SCAN_STAMP(3);                                                   // .. prefix scan + thresholds
             // ---- recurrence over the steps j = 1 .. nb-1, UNR steps per iteration with all their LDS reads issued up front.
             // No barrier inside: lanes leave the loop on their own (first flagged trial, or the end of their frame's block).
@@ -664,19 +704,35 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                         atomicMin(cflag, cand);
                     }
                 };
+                auto advance = [&](const cf (&dd)[SG::UNR], const cf (&gg)[SG::UNR][QM]) {   // the recurrence alone
+#pragma unroll
+                    for (int s_ = 0; s_ < SG::UNR; ++s_) {
+#pragma unroll
+                        for (int q = 0; q < QM; ++q) cfma(u[q], dd[s_], gg[s_][q]);
+                    }
+                };
                 int j = 1;
                 int lim = nb;
+                bool tests = true;                                       // per-step threshold tests in this window (wave-uniform)
                 if (j < lim) fetch(j, dA, tA, gA);
                 while (j < lim) {
+                    if (((j - 1) & (SG::CK - 1)) == 0) {
+                        const float tc = tchk[(j - 1) / SG::CK];
+                        bool h = false;
+#pragma unroll
+                        for (int q = 0; q < QM; ++q)
+                            h |= (unsigned(t + T * q - j) <= unsigned(cp + SG::CK - 1)) && (cnorm2(u[q]) > tc);
+                        tests = __builtin_amdgcn_ballot_w64(h) != 0;
+                    }
                     fetch(j + SG::UNR, dB, tB, gB);                      // reads past the block's end hit the padding
                     const int seen = *cflag;
-                    step(j, dA, tA, gA);
+                    if (tests) step(j, dA, tA, gA); else advance(dA, gA);
                     j += SG::UNR;
                     lim = min(lim, seen);
                     if (cand != 0x7fffffff || j >= lim) break;
                     fetch(j + SG::UNR, dA, tA, gA);
                     const int seen2 = *cflag;
-                    step(j, dB, tB, gB);
+                    if (tests) step(j, dB, tB, gB); else advance(dB, gB);
                     j += SG::UNR;
                     lim = min(lim, seen2);
                     if (cand != 0x7fffffff) break;
