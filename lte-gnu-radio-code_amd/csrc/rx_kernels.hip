@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, Sy
 // (the same sync_trial as everywhere else); a trial whose screened peak exceeds (1 - 1e-3) * gate * MM -- or whose window
 // energy is too small for the sliding sums to be trusted -- is re-evaluated exactly, in order, and only the exact value
 // decides (:166).  Trials the screen rejects lie at least 1e-3 * gate * MM below the gate, two orders of magnitude more
-// than the recurrence can drift over one block (<= 128 steps of ~6e-8 relative rounding), so the accepted trial and its
+// than the recurrence can drift over one block (<= 256 steps of ~6e-8 relative rounding), so the accepted trial and its
 // lag are those of the exhaustive search.  Frames whose sync sits at trial 0 never enter the recurrence.
 // Preconditions checked by the host: S == 1, stride == 1, Ks == N - 2, no rotator, B + cp <= SCAN_QM * T.
 template <int N>
