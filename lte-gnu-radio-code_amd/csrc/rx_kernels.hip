@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, Sy
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int slot = tid / T;
+    const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;    // a wave lies inside one slot: uniform
     const int t = tid % T;
     cf* smem = reinterpret_cast<cf*>(smem_raw);
     cf* lds = smem + slot * WgLds<N>::STRIDE;
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     constexpr int T = PL::T, P = PL::P, QM = SG::QM, SLOTS = PL::SLOTS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int slot = tid / T;
+    const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;    // a wave lies inside one slot: uniform
     const int t = tid % T;
     cf* smem = reinterpret_cast<cf*>(smem_raw);
     cf* lds = smem + slot * WgLds<N>::STRIDE;

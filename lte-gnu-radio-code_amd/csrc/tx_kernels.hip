@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned read_bits(const uint8_t* bits, int mode, int
 }
 
 // ---- the bit words of one lane's P bins.  KIND is compile-time: 2 / 4 / 6 = bits per constellation symbol of a one-bit-per-
-// byte stream whose frames start 4-byte aligned (one or three wide loads per bin, ALL issued before the first is used: loads
+// byte stream whose frames start 4-byte aligned (one or two wide loads per bin, ALL issued before the first is used: loads
 // behind per-bin branches go out one at a time, each waiting for the one before -- 16 memory latencies per symbol);
 // 10 / 12 / 14 = 8 + bits per symbol of a packed stream (8 bits per byte, MSB first: one or two byte loads per bin);
 // 0 = anything else (BPSK, unaligned one-bit-per-byte streams), read bit by bit.
@@ -64,7 +64,7 @@ __device__ __forceinline__ void keep_loads(unsigned (&r)[P]) {
 
 template <int P, int KIND>
 struct TxFetch {
-    unsigned w[KIND == 6 ? 3 : (KIND == 14 ? 2 : 1)][P];
+    unsigned w[(KIND == 6 || KIND == 14) ? 2 : 1][P];
 };
 __host__ __device__ __forceinline__ int tx_fetch_kind(int mode, int bps, bool al4) {
     if (bps != 2 && bps != 4 && bps != 6) return 0;
@@ -82,10 +82,13 @@ __device__ __forceinline__ void tx_fetch_issue(const uint8_t* bits, unsigned bas
     } else if constexpr (KIND == 6) {
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const uint16_t* p = reinterpret_cast<const uint16_t*>(bits + (base + max(li[q], 0)) * 6u);
-            f.w[0][q] = p[0];
-            f.w[1][q] = p[1];
-            f.w[2][q] = p[2];
+            // six bytes at a 2-byte-aligned address: one (unaligned) dword + one short, kept as loaded -- any arithmetic between
+            // a load and the point where all of them are in flight would make each bin wait for its own load
+            const uint8_t* p = bits + (base + max(li[q], 0)) * 6u;
+            uint32_t lo;
+            __builtin_memcpy(&lo, p, 4);
+            f.w[0][q] = lo;
+            f.w[1][q] = *reinterpret_cast<const uint16_t*>(p + 4);
         }
     } else if constexpr (KIND == 12 || KIND == 10) {
         constexpr unsigned sh = KIND == 12 ? 1u : 2u;                       // symbols per byte = 1 << sh
@@ -102,7 +105,6 @@ __device__ __forceinline__ void tx_fetch_issue(const uint8_t* bits, unsigned bas
     // one empty asm with every result as an operand: the loads above are all issued before the first of them is used
     if constexpr (KIND != 0) keep_loads(f.w[0]);
     if constexpr (KIND == 6 || KIND == 14) keep_loads(f.w[1]);
-    if constexpr (KIND == 6) keep_loads(f.w[2]);
 }
 // the bps-bit value, MSB first
 template <int P, int KIND>
@@ -114,8 +116,9 @@ __device__ __forceinline__ unsigned tx_fetch_value(const uint8_t* bits, int mode
     } else if constexpr (KIND == 2) {
         return ((f.w[0][q] & 1u) << 1) | ((f.w[0][q] >> 8) & 1u);
     } else if constexpr (KIND == 6) {
-        return ((f.w[0][q] & 1u) << 5) | (((f.w[0][q] >> 8) & 1u) << 4) | ((f.w[1][q] & 1u) << 3) | (((f.w[1][q] >> 8) & 1u) << 2) |
-               ((f.w[2][q] & 1u) << 1) | ((f.w[2][q] >> 8) & 1u);
+        const uint32_t lo = f.w[0][q], hi = f.w[1][q];
+        return ((lo & 1u) << 5) | (((lo >> 8) & 1u) << 4) | (((lo >> 16) & 1u) << 3) | (((lo >> 24) & 1u) << 2) | ((hi & 1u) << 1) |
+               ((hi >> 8) & 1u);
     } else if constexpr (KIND == 12) {
         return (f.w[0][q] >> (4u - ((base + max(li, 0)) & 1u) * 4u)) & 15u;
     } else if constexpr (KIND == 10) {
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int slot = tid / T;
+    const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;    // a wave lies inside one slot: uniform
     const int t = tid % T;
     cf* smem = reinterpret_cast<cf*>(smem_raw);
     cf* lds = smem + slot * WgLds<N>::STRIDE;
@@ -303,16 +306,23 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
         const uint8_t* fbits = a.bits ? a.bits + int64_t(frame) * a.bits_stride : nullptr;
 
         // resource grid row X[n] (:135-183), conjugated: ifft(X) = conj(fft(conj(X))) / N.
-        // list index of bin n in binsP(K), -1 = unused.  The lane's bin numbers go through an opaque copy of t: hoisted out of
-        // the symbol loop, the 16 list indices and addresses cost ~100 VGPRs and the occupancy with them.
+        // List index of bin k in binsP(K) (-1 = unused), branch-free: positive half i = K/2 + k - 1 for 1 <= k <= K/2, negative
+        // half i = k - (N - K/2) for k >= N - K/2; a bin listed twice (K == N: bin N/2) keeps its later, positive-half entry
+        // (the same rule as data_bin_index).  The lane's bin numbers go through an opaque copy of t: hoisted out of the symbol
+        // loop, the 16 list indices and addresses cost ~100 VGPRs and the occupancy with them.
         int tt = t;
         asm volatile("" : "+v"(tt));
+        const int hk = (is_sync ? tx.Ks : tx.Kd) >> 1;
+        const int off_pos = hk - 1, off_neg = hk - N;
         int li[P];
+        float use[P];                                                     // 1 for a used bin of an active symbol, else 0
 #pragma unroll
         for (int n0 = 0; n0 < P; ++n0) {
-            int i;
-            const bool has = data_bin_index(tt + T * n0, is_sync ? tx.Ks : tx.Kd, N, i);     // a bin listed twice keeps the later entry
-            li[n0] = (has && active) ? i : -1;
+            const int k = tt + T * n0;
+            const bool pos = unsigned(k - 1) < unsigned(hk), neg = k >= N - hk;
+            const bool used = (pos || neg) && active;
+            li[n0] = used ? k + (pos ? off_pos : off_neg) : -1;
+            use[n0] = used ? 1.f : 0.f;
         }
         cf v[P];
         if (is_sync) {
@@ -327,15 +337,15 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
             keep_loads(zr);
             keep_loads(zi);
 #pragma unroll
-            for (int n0 = 0; n0 < P; ++n0)
-                v[n0] = li[n0] < 0 ? cf{0.f, 0.f} : cf{__uint_as_float(zr[n0]), -__uint_as_float(zi[n0])};
+            for (int n0 = 0; n0 < P; ++n0) v[n0] = cf{__uint_as_float(zr[n0]) * use[n0], -__uint_as_float(zi[n0]) * use[n0]};
         } else if (fbits) {
             TxFetch<P, KIND> f;
             tx_fetch_issue<P, KIND>(fbits, base, li, f);
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) {
-                const unsigned val = tx_fetch_value<P, KIND>(fbits, a.bits_mode, tx.bps, base, li[n0], f, n0);
-                v[n0] = li[n0] < 0 ? cf{0.f, 0.f} : cconj(map_symbol(val, KIND != 0 ? (KIND & 7) : tx.bps));
+                // (mask by multiplication: a select around the mapping turns into a branch per bin)
+                const cf X = map_symbol(tx_fetch_value<P, KIND>(fbits, a.bits_mode, tx.bps, base, li[n0], f, n0), KIND != 0 ? (KIND & 7) : tx.bps);
+                v[n0] = cf{X.x * use[n0], -X.y * use[n0]};
             }
         } else {
 #pragma unroll
@@ -417,7 +427,7 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_time_kernel(TxDev tx, TimeArgs
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int slot = tid / T;
+    const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;    // a wave lies inside one slot: uniform
     const int t = tid % T;
     cf* smem = reinterpret_cast<cf*>(smem_raw);
     cf* lds = smem + slot * WgLds<N>::STRIDE;
