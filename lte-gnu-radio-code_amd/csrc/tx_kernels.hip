@@ -479,31 +479,44 @@ __global__ void __launch_bounds__(256) tx_mux_kernel(TxDev tx, MuxArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ channel
+// Two consecutive output samples per thread: one Philox4x32-10 block (four 32-bit words) feeds both Box-Muller pairs, and the
+// pair leaves in one 16-byte store where the row is aligned.  Noise is N(0, noise_std^2) per component from the hardware
+// transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 take their argument in revolutions): a statistical model of
+// MultiAntennaSystem.py:258, not a bit-pinned one.
 __global__ void __launch_bounds__(256) channel_kernel(ChanArgs a) {
     const int frame = blockIdx.y;
     const cf* in = a.in + int64_t(frame) * a.in_stride;
     const cf* taps = a.taps + (a.per_frame_taps ? int64_t(frame) * a.n_taps : 0);
     cf* out = a.out + int64_t(frame) * a.out_stride;
-    for (int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; n < a.out_len;
-         n += int64_t(gridDim.x) * blockDim.x) {
-        cf acc = cf{0.f, 0.f};
+    const bool wide = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const int64_t n_pairs = (a.out_len + 1) >> 1;
+    for (int64_t pr = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; pr < n_pairs; pr += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t n = pr * 2;
+        cf acc0 = cf{0.f, 0.f}, acc1 = cf{0.f, 0.f};
         for (int l = 0; l < a.n_taps; ++l) {                          // np.convolve(tx_sig, chan) :227
+            const cf h = taps[l];
             const int64_t j = n - l;
-            if (j >= 0 && j < a.in_len) acc = acc + cmul(taps[l], in[j]);
+            if (j >= 0 && j < a.in_len) acc0 = acc0 + cmul(h, in[j]);
+            if (j + 1 >= 0 && j + 1 < a.in_len) acc1 = acc1 + cmul(h, in[j + 1]);
         }
         if (a.noise_std > 0.f) {                                      // :258
             uint32_t rnd[4];
-            philox4x32_10(uint32_t(n), uint32_t(uint64_t(n) >> 32), uint32_t(frame), 0u, uint32_t(a.seed),
-                          uint32_t(a.seed >> 32), rnd);
-            const float u1 = (float(rnd[0]) + 0.5f) * 2.3283064365386963e-10f;
-            const float u2 = (float(rnd[1]) + 0.5f) * 2.3283064365386963e-10f;
-            const float rr = sqrtf(-2.f * logf(u1));
-            float sn, cs;
-            sincosf(6.283185307179586f * u2, &sn, &cs);
-            acc.x += a.noise_std * rr * cs;
-            acc.y += a.noise_std * rr * sn;
+            philox4x32_10(uint32_t(pr), uint32_t(uint64_t(pr) >> 32), uint32_t(frame), 0u, uint32_t(a.seed), uint32_t(a.seed >> 32), rnd);
+            constexpr float k = 2.3283064365386963e-10f;              // 2^-32
+            const float r0 = a.noise_std * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf((float(rnd[0]) + 0.5f) * k));
+            const float r1 = a.noise_std * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf((float(rnd[2]) + 0.5f) * k));
+            const float u0 = (float(rnd[1]) + 0.5f) * k, u1 = (float(rnd[3]) + 0.5f) * k;     // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+            acc0.x += r0 * __builtin_amdgcn_cosf(u0);
+            acc0.y += r0 * __builtin_amdgcn_sinf(u0);
+            acc1.x += r1 * __builtin_amdgcn_cosf(u1);
+            acc1.y += r1 * __builtin_amdgcn_sinf(u1);
         }
-        out[n] = acc;
+        if (wide && n + 1 < a.out_len) {
+            *reinterpret_cast<float4*>(out + n) = float4{acc0.x, acc0.y, acc1.x, acc1.y};
+        } else {
+            out[n] = acc0;
+            if (n + 1 < a.out_len) out[n + 1] = acc1;
+        }
     }
 }
 
