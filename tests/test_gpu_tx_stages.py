@@ -157,3 +157,39 @@ def test_blocks_chained_like_the_flowgraph(golden):
     b1, b2 = np.zeros(1000, np.uint8), np.zeros(500, np.uint8)
     assert src.work([], [b1]) == 1000 and src.work([], [b2]) == 500
     assert np.array_equal(np.concatenate([b1, b2]), orc.random_bits(42, 0, 1500))
+
+
+@pytest.mark.parametrize("N,cp,Kd,mod", [(64, 15, 60, "16QAM"), (256, 19, 180, "64QAM"), (2048, 143, 1200, "QPSK"),
+                                          (2048, 144, 1200, "64QAM"), (1024, 72, 600, "16QAM")])
+def test_fused_modulator_layout_fallbacks_equal_the_oracle(om, N, cp, Kd, mod):
+    """The fused kernel picks its fast paths from the layout it is handed: wide bit loads need the stream 4-byte aligned, the
+    16-byte stores an even cp and symbol length and an aligned output.  An odd cp, an output that starts 8 bytes into a 16-byte
+    line, an odd frame stride and a bit stream at an odd address must give the same samples as the aligned call and the oracle."""
+    import torch
+    n_sym, n_frames = 8, 3
+    L = N + cp
+    rng = np.random.default_rng(N + cp)
+    tx = om.TxEngine(N, cp, N - 2, Kd, (1, 3), mod)
+    nb = tx.bits_per_frame(n_sym)
+    bits = rng.integers(0, 2, (n_frames, nb)).astype(np.uint8)
+    ref = np.stack([orc.tx_modulate(bits[f], N, cp, N - 2, Kd, n_sym, modulation=mod) for f in range(n_frames)])
+    dev = torch.device("cuda", 0)
+    # aligned call
+    d_bits = torch.from_numpy(bits).to(dev)
+    d_iq = torch.zeros((n_frames, n_sym * L, 2), dtype=torch.float32, device=dev)
+    tx.modulate_frames(d_bits.data_ptr(), n_frames, n_sym, d_iq.data_ptr())
+    torch.cuda.synchronize()
+    y0 = d_iq.cpu().numpy().view(np.complex64).reshape(n_frames, n_sym * L)
+    assert relerr(y0, ref) < TOL
+    # bit stream at an odd address (frames back to back: the stride nb keeps every frame misaligned too when nb is even)
+    raw = torch.zeros(n_frames * nb + 8, dtype=torch.uint8, device=dev)
+    raw[1:1 + n_frames * nb] = d_bits.reshape(-1)
+    # output 8 bytes into a 16-byte line, frames one sample further apart than they need to be (odd stride)
+    stride = n_sym * L + 1
+    out = torch.zeros((n_frames * stride + 4, 2), dtype=torch.float32, device=dev)
+    tx.modulate_frames(raw.data_ptr() + 1, n_frames, n_sym, out.data_ptr() + 8, frame_stride=stride)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().view(np.complex64).reshape(-1)
+    y1 = np.stack([o[1 + f * stride:1 + f * stride + n_sym * L] for f in range(n_frames)])
+    assert np.array_equal(y1, y0)
+    assert o[0] == 0 and all(o[1 + f * stride + n_sym * L] == 0 for f in range(n_frames))     # nothing written outside the frames
