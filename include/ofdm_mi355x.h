@@ -300,6 +300,12 @@ int ofdm_trk_demod(ofdm_trk* h, int32_t n_sync, const int64_t* h_ptr, const uint
 int ofdm_trk_get_state(ofdm_trk* h, float* h_chan_freq, float* h_chan_impulse, float* h_synch_freq, float* h_data_freq);
 
 /* ------------------------------------------------------------------------------------------ misc */
+/* *d_count += number of differing bits of two device byte strings (packed bit-streams): the BER numerator without moving
+ * the streams -- with frames sharded over GPUs the ranks then exchange 8 bytes instead of their bits.  The
+ * reference's idiom is bitwise_xor(a, b).sum() (TEST/GNU_RADIO_OFFLINE/pls_aio.py:131).  d_count is a DEVICE uint64 the
+ * caller zeroes; asynchronous on `stream` (NULL: the default stream).  n_bytes <= 2^40. */
+int ofdm_count_bit_errors(int32_t device, const uint8_t* d_a, const uint8_t* d_b, int64_t n_bytes, uint64_t* d_count, void* stream);
+
 /* Measurement aid for bench.py: mode 0 = float4 device copy of `bytes` (achievable HBM rate of this chip, same run);
  * mode 1 = the demod kernel's access pattern without arithmetic (per symbol: skip gap_bytes, read sym_in_bytes, write
  * sym_out_bytes).  Asynchronous on `stream`. */

@@ -852,6 +852,14 @@ int ofdm_bandwidth_probe(int32_t device, const void* d_in, void* d_out, int64_t 
     return OFDM_OK;
 }
 
+int ofdm_count_bit_errors(int32_t device, const uint8_t* d_a, const uint8_t* d_b, int64_t n_bytes, uint64_t* d_count, void* stream) {
+    if (!d_count || n_bytes < 0 || (n_bytes > 0 && (!d_a || !d_b))) return fail(OFDM_ERR_INVALID, "ofdm_count_bit_errors: bad argument");
+    if (n_bytes > (int64_t(1) << 40)) return fail(OFDM_ERR_INVALID, "ofdm_count_bit_errors: more than 2^40 bytes per call");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(launch_bit_errors(d_a, d_b, n_bytes, reinterpret_cast<unsigned long long*>(d_count), static_cast<hipStream_t>(stream)));
+    return OFDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------ TX
 // ================================================================== CFO-search receiver
 int ofdm_fo_destroy(ofdm_fo* h) {

@@ -131,6 +131,7 @@ struct ChanArgs {
 hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s);
 hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s);
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s);
+hipError_t launch_bit_errors(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* count, hipStream_t s);
 // out[row][i] = mean_SF( in[row][SF + i*dsss] * conj(code[SF]) ), i < n_spread  (SynchEstFOAndDSSS.py:391-399)
 // rows visited in order; row r of frame f = f*D + n is divided by sqrt(mean |row f|^2) (SynchronizeAndEstimate.py:431-434)
 hipError_t launch_row_renorm(cf* eq, int Kd, int D, int n_frames, const int* tsr, hipStream_t s);

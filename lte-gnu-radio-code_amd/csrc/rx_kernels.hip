@@ -798,6 +798,33 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
 #undef SCAN_STAMP
 }
 
+// ------------------------------------------------------------------------------------------ bit-error count
+// count += popcount(a ^ b) over n bytes: the BER numerator of two packed bit-streams without moving them anywhere (SURVEY 8e:
+// "gather counts instead"; the reference's idiom is bitwise_xor(a, b).sum(), TEST/GNU_RADIO_OFFLINE/pls_aio.py:131).
+__global__ void __launch_bounds__(256) bit_errors_kernel(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* count) {
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    const int64_t n16 = wide ? n / 16 : 0;
+    unsigned c = 0;                                                   // <= 128 per step: a lane would need 2^25 steps to overflow
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint4* b4 = reinterpret_cast<const uint4*>(b);
+    for (int64_t i = gid; i < n16; i += stride) {
+        const uint4 x = a4[i], y = b4[i];
+        c += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+    }
+    for (int64_t i = n16 * 16 + gid; i < n; i += stride) c += __popc(unsigned(a[i] ^ b[i]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, static_cast<unsigned long long>(c));
+}
+
+hipError_t launch_bit_errors(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* count, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>((n / 16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(bit_errors_kernel, dim3(unsigned(blocks)), dim3(256), 0, s, a, b, n, count);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ standalone de-mapper
 __global__ void demap_hard_kernel(DemapArgs a) {
     const int64_t n = a.n;

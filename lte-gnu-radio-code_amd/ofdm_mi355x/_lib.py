@@ -82,6 +82,7 @@ PROTOTYPES = {
     "ofdm_device_synchronize": (C.c_int, [C.c_int32]),
     "ofdm_bandwidth_probe": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int64, C.c_void_p]),
+    "ofdm_count_bit_errors": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ofdm_rx_create": (C.c_int, [C.POINTER(RxCfg), C.POINTER(C.c_void_p)]),
     "ofdm_rx_destroy": (C.c_int, [C.c_void_p]),
     "ofdm_rx_work": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(RxReport)]),

@@ -74,6 +74,11 @@ class DeviceBuffer:
             pass
 
 
+def count_bit_errors(d_a, d_b, n_bytes: int, d_count, stream=None, device: int = 0):
+    """*d_count (device uint64, zeroed by the caller) += popcount(a ^ b) over n_bytes of two device byte strings."""
+    check(_lib.load().ofdm_count_bit_errors(int(device), ptr(d_a), ptr(d_b), int(n_bytes), ptr(d_count), ptr(stream)))
+
+
 class RxEngine:
     """Receive chain handle (sync search, LS channel estimate, FFT + equalise, de-map)."""
 

@@ -428,3 +428,25 @@ def test_full_size_batch_properties(om, config):
     num = float((eq4 - eq1).abs().max().item())
     den = float(eq1.abs().max().item())
     assert num / den < TOL
+
+
+@pytest.mark.parametrize("n,off_a,off_b", [(0, 0, 0), (1, 0, 0), (15, 0, 0), (16, 0, 0), (17, 0, 0), (4097, 0, 0), ((1 << 20) + 3, 0, 0),
+                                            (70001, 1, 0), (70001, 3, 7), (1 << 16, 16, 32)])
+def test_count_bit_errors_equals_numpy(om, n, off_a, off_b):
+    """popcount(a ^ b) over two device byte strings (the multi-GPU BER numerator): exact for every length, tail and
+    alignment; the counter accumulates across calls."""
+    import torch
+    rng = np.random.default_rng(n + off_a)
+    a = rng.integers(0, 256, n + 64, dtype=np.uint8)
+    b = a.copy()
+    flip = rng.random(n + 64) < 0.1
+    b[flip] ^= rng.integers(1, 256, int(flip.sum()), dtype=np.uint8)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    want = int(np.unpackbits(a[off_a:off_a + n] ^ b[off_b:off_b + n]).sum())
+    om.count_bit_errors(da.data_ptr() + off_a, db.data_ptr() + off_b, n, cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == want
+    om.count_bit_errors(da.data_ptr() + off_a, db.data_ptr() + off_b, n, cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 2 * want
