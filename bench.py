@@ -463,41 +463,46 @@ def main(argv=None):
         # SURVEY 8(e) "report both": the same step with bit-error COUNTS exchanged instead of the bits -- every rank counts its
         # shard's errors against the transmitted bits on the device and the ranks all-reduce 8 bytes.  Not `value`: it shows what
         # the frame shards give when the fabric carries nothing.
-        k2 = max(1, min(args.steps, 50))
-        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-        tx_bits = [inp[1] for inp in inputs]
+        counts_only = None
+        try:
+            k2 = max(1, min(args.steps, 50))
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            tx_bits = [inp[1] for inp in inputs]
 
-        def count_step():
-            bits = pipe.bits[0]
-            cnt.zero_()
-            for (r0, r1) in bounds:
-                produce(bits, r0, r1)
-                b, f0 = divmod(r0, n_frames)
-                om.count_bit_errors(bits[r0:r1], tx_bits[b][f0:f0 + (r1 - r0)], (r1 - r0) * bytes_per_frame_bits, cnt, stream)
-            tot = cnt.cpu() if rehearsal else cnt.clone()
-            dist.all_reduce(tot)
-            return tot
-        count_step()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        for _ in range(k2):
-            tot = count_step()
-        torch.cuda.synchronize()
-        dist.barrier()
-        c_ms = (time.perf_counter() - tc) / k2 * 1e3
-        tcm = torch.tensor([c_ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(tcm, op=dist.ReduceOp.MAX)
-        c_ms = float(tcm.item())
+            def count_step():
+                bits = pipe.bits[0]
+                cnt.zero_()
+                for (r0, r1) in bounds:
+                    produce(bits, r0, r1)
+                    b, f0 = divmod(r0, n_frames)
+                    om.count_bit_errors(bits[r0:r1], tx_bits[b][f0:f0 + (r1 - r0)], (r1 - r0) * bytes_per_frame_bits, cnt, stream)
+                tot = cnt.cpu() if rehearsal else cnt.clone()
+                dist.all_reduce(tot)
+                return tot
+            count_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(k2):
+                tot = count_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            c_ms = (time.perf_counter() - tc) / k2 * 1e3
+            tcm = torch.tensor([c_ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tcm, op=dist.ReduceOp.MAX)
+            c_ms = float(tcm.item())
+            counts_only = dict(what="same step, bit-error counts all-reduced (8 B per rank) instead of the bits all-gathered",
+                               steps=k2, ms_per_step=round(c_ms, 4), value_Msamples_per_s=round(samples_per_step / (c_ms * 1e-3) / 1e6, 1),
+                               bit_errors_all_ranks=int(tot.item()), bits_all_ranks=int(d_bits.numel()) * 8 * world)
+        except Exception as e:                      # never lose the measured line to the extra leg
+            counts_only = dict(error="%s: %s" % (type(e).__name__, e))
         gather_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
                            rccl_version=_rccl_version(torch) if not rehearsal else None,
                            bytes_contributed_per_rank_and_step=int(d_bits.numel()), bytes_received_per_rank_and_step=int(d_bits.numel() * (world - 1)),
                            allgather_alone_ms=round(g_ms, 4), allgather_alone_busbw_GBs=round(nb * (world - 1) / (g_ms * 1e-3) / 1e9, 2),
                            allgather_in_loop_GBs_received_per_rank=round(d_bits.numel() * (world - 1) / (ms_per_step * 1e-3) / 1e9, 2),
-                           counts_only=dict(what="same step, bit-error counts all-reduced (8 B per rank) instead of the bits all-gathered",
-                                            steps=k2, ms_per_step=round(c_ms, 4), value_Msamples_per_s=round(samples_per_step / (c_ms * 1e-3) / 1e6, 1),
-                                            bit_errors_all_ranks=int(tot.item()), bits_all_ranks=int(d_bits.numel()) * 8 * world))
+                           counts_only=counts_only)
 
     out = None
     if rank == 0:
