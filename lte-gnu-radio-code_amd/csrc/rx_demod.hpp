@@ -188,21 +188,116 @@ __device__ __forceinline__ unsigned pack4(const cf (&z)[4]) {
     return w;
 }
 
+// The same for 2 consecutive symbols (2*MOD bits): the dense output mapping hands a lane pairs of list entries.
+template <int MOD, bool ASMB = true>
+__device__ __forceinline__ unsigned pack2(const cf (&z)[2]) {
+    unsigned w = 0;
+    if constexpr (!ASMB || MOD == 1) {
+        w = (hard_bits<MOD>(z[0]) << MOD) | hard_bits<MOD>(z[1]);
+    } else if constexpr (MOD == 4) {
+        constexpr float t = 0.63245553203367588f;   // 2/sqrt(10)
+        unsigned long long m0, m1, m2, m3;
+#define OFDM_Q16(RE, IM)                                   \
+    "v_cmp_gt_f32_e64 %1, 0, " RE "\n\t"                   \
+    "v_cmp_gt_f32_e64 %2, 0, " IM "\n\t"                   \
+    "v_cmp_gt_f32_e64 %3, |" RE "|, %9\n\t"                \
+    "v_cmp_gt_f32_e64 %4, |" IM "|, %9\n\t"                \
+    "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"             \
+    "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"             \
+    "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"             \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+        asm(OFDM_Q16("%5", "%6") OFDM_Q16("%7", "%8")
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+            : "v"(z[0].x), "v"(z[0].y), "v"(z[1].x), "v"(z[1].y), "s"(t));
+#undef OFDM_Q16
+    } else if constexpr (MOD == 6) {
+        constexpr float a = 0.61721339984836765f;    // 4/sqrt(42)
+        constexpr float c = 0.30860669992418382f;    // 2/sqrt(42)
+        unsigned long long m0, m1, m2, m3, m4, m5;
+        float tr, ti;
+#define OFDM_Q64(RE, IM)                                   \
+    "v_sub_f32_e64 %7, |" RE "|, %13\n\t"                  \
+    "v_sub_f32_e64 %8, |" IM "|, %13\n\t"                  \
+    "v_cmp_gt_f32_e64 %1, 0, " RE "\n\t"                   \
+    "v_cmp_gt_f32_e64 %2, 0, " IM "\n\t"                   \
+    "v_cmp_gt_f32_e64 %3, |" RE "|, %13\n\t"               \
+    "v_cmp_gt_f32_e64 %4, |" IM "|, %13\n\t"               \
+    "v_cmp_gt_f32_e64 %5, |%7|, %14\n\t"                   \
+    "v_cmp_gt_f32_e64 %6, |%8|, %14\n\t"                   \
+    "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"             \
+    "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"             \
+    "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"             \
+    "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"             \
+    "v_addc_co_u32_e64 %0, %5, %0, %0, %5\n\t"             \
+    "v_addc_co_u32_e64 %0, %6, %0, %0, %6\n\t"
+        asm(OFDM_Q64("%9", "%10") OFDM_Q64("%11", "%12")
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&v"(tr), "=&v"(ti)
+            : "v"(z[0].x), "v"(z[0].y), "v"(z[1].x), "v"(z[1].y), "s"(a), "s"(c));
+#undef OFDM_Q64
+    } else {                                         // MOD == 2
+        constexpr float t = 1.41421354f;             // largest float32 below sqrt(2): BitRecovery's outlier edge
+        // a coordinate that is exactly zero (a tie of the reference's nearest-point search) takes the literal path
+        if (z[0].x * z[0].y * z[1].x * z[1].y == 0.f) {
+            const bool tie = (z[0].x == 0.f) | (z[0].y == 0.f) | (z[1].x == 0.f) | (z[1].y == 0.f);
+            if (tie) return (hard_bits<2>(z[0]) << 2) | hard_bits<2>(z[1]);
+        }
+        unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+        asm("v_cmp_gt_f32_e64 %1, 0, %9\n\t"
+            "v_cmp_gt_f32_e64 %2, |%9|, %13\n\t"
+            "v_cmp_gt_f32_e64 %3, 0, %10\n\t"
+            "v_cmp_gt_f32_e64 %4, |%10|, %13\n\t"
+            "v_cmp_gt_f32_e64 %5, 0, %11\n\t"
+            "v_cmp_gt_f32_e64 %6, |%11|, %13\n\t"
+            "v_cmp_gt_f32_e64 %7, 0, %12\n\t"
+            "v_cmp_gt_f32_e64 %8, |%12|, %13\n\t"
+            "s_xor_b64 %1, %1, %2\n\t"
+            "s_xor_b64 %3, %3, %4\n\t"
+            "s_xor_b64 %5, %5, %6\n\t"
+            "s_xor_b64 %7, %7, %8\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"
+            "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"
+            "v_addc_co_u32_e64 %0, %5, %0, %0, %5\n\t"
+            "v_addc_co_u32_e64 %0, %7, %0, %0, %7\n\t"
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+            : "v"(z[0].x), "v"(z[0].y), "v"(z[1].x), "v"(z[1].y), "s"(t)
+            : "scc");
+    }
+    return w;
+}
+
+// one-bit-per-byte output of the PAIR of list entries sym0, sym0 + 1 held by one lane (dense output mapping)
+template <int MOD>
+__device__ __forceinline__ void store_bits_pair_unpacked(uint8_t* bits, int64_t sym0, const cf (&z)[2]) {
+    uint8_t* o = bits + sym0 * MOD;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned hb = hard_bits<MOD>(z[e]);
+#pragma unroll
+        for (int b = 0; b < MOD; ++b) o[e * MOD + b] = uint8_t((hb >> (MOD - 1 - b)) & 1u);
+    }
+}
+
+// the 4*MOD bits `w` of the list entries sym0 .. sym0 + 3 (sym0 % 4 == 0), MSB first, as MOD/2 bytes
+template <int MOD>
+__device__ __forceinline__ void store_packed4(uint8_t* bits, int64_t sym0, unsigned w) {
+    uint8_t* o = bits + sym0 * MOD / 8;
+    if constexpr (MOD == 2) {
+        o[0] = uint8_t(w);
+    } else if constexpr (MOD == 4) {
+        *reinterpret_cast<uint16_t*>(o) = uint16_t(((w & 0xffu) << 8) | (w >> 8));
+    } else {
+        o[0] = uint8_t(w >> 16);
+        o[1] = uint8_t(w >> 8);
+        o[2] = uint8_t(w);
+    }
+}
+
 // writes the bits of 4 (or `cnt`) consecutive list entries starting at list index idx of output row `orow`
 template <int MOD, int BMODE, bool ASMB = true>
 __device__ __forceinline__ void store_bits(uint8_t* bits, int64_t sym0, const cf (&z)[4], int cnt) {
     if constexpr (BMODE == 1) {            // packed MSB-first: 4 symbols -> MOD/2 bytes (host guarantees Kd % 4 == 0, MOD even)
-        const unsigned w = pack4<MOD, ASMB>(z);
-        uint8_t* o = bits + sym0 * MOD / 8;
-        if constexpr (MOD == 2) {
-            o[0] = uint8_t(w);
-        } else if constexpr (MOD == 4) {
-            *reinterpret_cast<uint16_t*>(o) = uint16_t(((w & 0xffu) << 8) | (w >> 8));
-        } else {
-            o[0] = uint8_t(w >> 16);
-            o[1] = uint8_t(w >> 8);
-            o[2] = uint8_t(w);
-        }
+        store_packed4<MOD>(bits, sym0, pack4<MOD, ASMB>(z));
     } else if constexpr (BMODE == 2) {     // one bit per byte
         uint8_t* o = bits + sym0 * MOD;
 #pragma unroll
@@ -243,6 +338,8 @@ enum DemodFlags : unsigned {
     DF_L2_INPUT = 1u << 7,       // every workgroup reads frame (blockIdx % 8): cache-resident input, WRONG results, timing only
     DF_LANE_TWIDDLES = 1u << 8,  // all 15 pass-0 twiddles of a lane in VGPRs instead of 4 base values + products
     DF_PSUM_READBACK = 1u << 9,  // power sum by a separate LDS read pass over the staged list (round-1 form)
+    DF_FOUR_PER_LANE = 1u << 10, // output mapping of round 1 at every size: a lane owns 4 consecutive list entries (two 16 B
+                                 // stores 32 B apart: every store instruction of a wave covers 2 KB half-filled)
 };
 
 template <int N, int MOD, int BMODE, int MINW, unsigned FLAGS = 0>
@@ -250,7 +347,10 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     constexpr bool ROT = (FLAGS & DF_ROT) != 0, HG = (FLAGS & DF_HG) != 0, GLDS = (FLAGS & DF_GAINS_GLOBAL) == 0,
                    NT = (FLAGS & DF_NT) != 0, ASMB = (FLAGS & DF_GENERIC_BITS) == 0, STAMP = (FLAGS & DF_STAMP) != 0,
                    PIPE = (FLAGS & DF_NO_PIPE) == 0, L2IN = (FLAGS & DF_L2_INPUT) != 0,
-                   CT = (FLAGS & DF_LANE_TWIDDLES) == 0 && Plan<N>::R0 == 16, PSE = (FLAGS & DF_PSUM_READBACK) == 0;
+                   CT = (FLAGS & DF_LANE_TWIDDLES) == 0 && Plan<N>::R0 == 16, PSE = (FLAGS & DF_PSUM_READBACK) == 0,
+                   // dense output mapping (N >= 1024): a lane owns two PAIRS of list entries 128 apart, so that each store
+                   // instruction of a wave covers 1 KB contiguously and the LDS list is read at a 16 B lane stride
+                   DENSE = Plan<N>::T >= 64 && (FLAGS & DF_FOUR_PER_LANE) == 0 && !(MOD == 1 && BMODE == 1);
     using PL = Plan<N>;
     using DG = DemodGeom<N>;
     constexpr int T = PL::T, P = PL::P, Q = P / 4, NS = DG::NS;
@@ -467,7 +567,49 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         const float scale = sqrtf(float(Kd_) / psum);                    // :233 p_est0
         stamp(5);                                                        // .. list read + power sum
 
-        if (compute) {
+        if constexpr (DENSE) {
+            if (compute) {
+                const int wv = t >> 6, ln = t & 63;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    unsigned wp[2] = {0u, 0u};                         // packed bits of this lane's two pairs
+                    int idxp[2];
+#pragma unroll
+                    for (int hx = 0; hx < 2; ++hx) {
+                        const int idx = 4 * T * q + 256 * wv + 128 * hx + 2 * ln;        // Kd is even: a pair is in or out as one
+                        idxp[hx] = idx;
+                        if (idx < Kd_) {
+                            const float4 g = *reinterpret_cast<const float4*>(gsrc + idx);
+                            const float4 av = *reinterpret_cast<const float4*>(lds + idx);
+                            // :235-248  x * p_est0 * e^{j..} * gain
+                            const cf z[2] = {cmul(cf{av.x, av.y} * scale, cf{g.x, g.y}), cmul(cf{av.z, av.w} * scale, cf{g.z, g.w})};
+                            if (a.eq) {
+                                const float4 o4 = float4{z[0].x, z[0].y, z[1].x, z[1].y};
+                                if constexpr (NT) {
+                                    typedef float f4 __attribute__((ext_vector_type(4)));
+                                    __builtin_nontemporal_store(f4{o4.x, o4.y, o4.z, o4.w}, reinterpret_cast<f4*>(a.eq + orow * Kd_ + idx));
+                                } else {
+                                    *reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx) = o4;
+                                }
+                            }
+                            if constexpr (BMODE == 1) wp[hx] = pack2<MOD, ASMB>(z);
+                            if constexpr (BMODE == 2) store_bits_pair_unpacked<MOD>(a.bits, orow * Kd_ + idx, z);
+                        }
+                    }
+                    if constexpr (BMODE == 1) {
+                        // Lanes 2m, 2m+1 hold the four consecutive entries of a group in BOTH halves: the even lane writes the group
+                        // of the first half, the odd lane the group of the second -- one exchange through a quad permute, then
+                        // the same whole-byte stores as with four entries per lane, every lane busy.  (Kd % 4 == 0: a group is in
+                        // or out as one.)
+                        const bool odd = (ln & 1) != 0;
+                        const unsigned recv = unsigned(__builtin_amdgcn_mov_dpp(int(odd ? wp[0] : wp[1]), 0xB1, 0xF, 0xF, false));   // quad_perm:[1,0,3,2]
+                        const unsigned w4 = odd ? ((recv << (2 * MOD)) | wp[1]) : ((wp[0] << (2 * MOD)) | recv);
+                        const int gidx = odd ? idxp[1] - 2 : idxp[0];
+                        if (gidx < Kd_) store_packed4<MOD>(a.bits, orow * Kd_ + gidx, w4);
+                    }
+                }
+            }
+        } else if (compute) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int idx = 4 * (t + T * q);
@@ -561,6 +703,13 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     // Tuning / diagnostic builds (tools/experiments: libofdm_mi355x_exp.so, ofdm_exp_set_variant): 16-QAM packed only.
     // None of them is compiled into the product library; an unknown variant falls through to the shipped kernel.
     if constexpr (N == 2048) {
+        if (a.variant == 13 && bmode == 1 && a.mod != 4) {          // round-1 output mapping at QPSK / 64-QAM (16-QAM: below)
+            if (a.mod == 6)
+                hipLaunchKernelGGL((rx_demod_kernel<N, 6, 1, 3, DF_FOUR_PER_LANE>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            else
+                hipLaunchKernelGGL((rx_demod_kernel<N, 2, 1, 3, DF_FOUR_PER_LANE>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            return hipGetLastError();
+        }
         if (a.variant != 0 && a.variant < 100 && bmode == 1 && a.mod == 4) {
 #define OFDM_LV(V, MW, FL, LDSB)                                                                                            \
     if (a.variant == V) {                                                                                                   \
@@ -577,6 +726,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             OFDM_LV(10, 3, DF_LANE_TWIDDLES | DF_PSUM_READBACK, lds) // the round-1 kernel
             OFDM_LV(11, 3, DF_PSUM_READBACK, lds)
             OFDM_LV(12, 3, DF_LANE_TWIDDLES, lds)
+            OFDM_LV(13, 3, DF_FOUR_PER_LANE, lds)                    // round-1 output mapping
 #undef OFDM_LV
         }
     }
