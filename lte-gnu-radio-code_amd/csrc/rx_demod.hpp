@@ -331,7 +331,8 @@ enum DemodFlags : unsigned {
     DF_ROT = 1u << 0,            // every window is multiplied by a carrier-offset rotator (SynchEstAndFO.py:339)
     DF_HG = 1u << 1,             // a frame is demodulated iff the host set its guard flag (tracker receiver)
     DF_GAINS_GLOBAL = 1u << 2,   // gains re-read from global memory per symbol instead of one LDS copy per chunk
-    DF_NT = 1u << 3,             // non-temporal hint on the stream loads and the output stores
+    DF_TEMPORAL_LD = 1u << 3,    // plain (cached) stream loads instead of the non-temporal hint ...
+    DF_TEMPORAL_ST = 1u << 11,   // ... and plain equalised-symbol stores (the pair of them is the round-1 / early round-2 kernel)
     DF_GENERIC_BITS = 1u << 4,   // plain C++ bit packing instead of the v_cmp / v_addc form
     DF_STAMP = 1u << 5,          // s_memtime stamps per phase (diagnostic, never timed)
     DF_NO_PIPE = 1u << 6,        // next symbol's loads issued at the loop top instead of right after the scatter
@@ -345,7 +346,10 @@ enum DemodFlags : unsigned {
 template <int N, int MOD, int BMODE, int MINW, unsigned FLAGS = 0>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
     constexpr bool ROT = (FLAGS & DF_ROT) != 0, HG = (FLAGS & DF_HG) != 0, GLDS = (FLAGS & DF_GAINS_GLOBAL) == 0,
-                   NT = (FLAGS & DF_NT) != 0, ASMB = (FLAGS & DF_GENERIC_BITS) == 0, STAMP = (FLAGS & DF_STAMP) != 0,
+                   // The IQ stream is read once and the equalised symbols are written once: both carry the non-temporal hint.
+                   // It pays only with the dense output mapping (a store instruction covering whole lines): -2.1 % there, while
+                   // on the half-filled 2 KB spans of the 4-entries-per-lane mapping it cost +7.6 %.  Below 1024-pt: plain.
+                   NTL = (FLAGS & DF_TEMPORAL_LD) == 0 && Plan<N>::T >= 64, NT = (FLAGS & DF_TEMPORAL_ST) == 0 && Plan<N>::T >= 64, ASMB = (FLAGS & DF_GENERIC_BITS) == 0, STAMP = (FLAGS & DF_STAMP) != 0,
                    PIPE = (FLAGS & DF_NO_PIPE) == 0, L2IN = (FLAGS & DF_L2_INPUT) != 0,
                    CT = (FLAGS & DF_LANE_TWIDDLES) == 0 && Plan<N>::R0 == 16, PSE = (FLAGS & DF_PSUM_READBACK) == 0,
                    // dense output mapping (N >= 1024): a lane owns two PAIRS of list entries 128 apart, so that each store
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         if (sy.compute && sy.start >= 0 && sy.start + N <= a.frame_len) {
             const cf* src = frame_iq + sy.start + t;
 #pragma unroll
-            for (int n0 = 0; n0 < P; ++n0) v[n0] = NT ? __builtin_nontemporal_load(src + T * n0) : src[T * n0];
+            for (int n0 = 0; n0 < P; ++n0) v[n0] = NTL ? __builtin_nontemporal_load(src + T * n0) : src[T * n0];
             if constexpr (ROT) {                                         // data_buff_time * cfo[idx]  (SynchEstAndFO.py:339)
 #pragma unroll
                 for (int n0 = 0; n0 < P; ++n0) v[n0] = cmul(v[n0], a.rot[t + T * n0]);
@@ -703,11 +707,16 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     // Tuning / diagnostic builds (tools/experiments: libofdm_mi355x_exp.so, ofdm_exp_set_variant): 16-QAM packed only.
     // None of them is compiled into the product library; an unknown variant falls through to the shipped kernel.
     if constexpr (N == 2048) {
-        if (a.variant == 13 && bmode == 1 && a.mod != 4) {          // round-1 output mapping at QPSK / 64-QAM (16-QAM: below)
-            if (a.mod == 6)
-                hipLaunchKernelGGL((rx_demod_kernel<N, 6, 1, 3, DF_FOUR_PER_LANE>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+        if ((a.variant == 13 || a.variant == 1) && bmode == 1 && a.mod != 4) {   // the same two at QPSK / 64-QAM (16-QAM: below)
+            constexpr unsigned PLAIN = DF_TEMPORAL_LD | DF_TEMPORAL_ST;
+            if (a.mod == 6 && a.variant == 13)
+                hipLaunchKernelGGL((rx_demod_kernel<N, 6, 1, 3, DF_FOUR_PER_LANE | PLAIN>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            else if (a.mod == 6)
+                hipLaunchKernelGGL((rx_demod_kernel<N, 6, 1, 3, PLAIN>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+            else if (a.variant == 13)
+                hipLaunchKernelGGL((rx_demod_kernel<N, 2, 1, 3, DF_FOUR_PER_LANE | PLAIN>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             else
-                hipLaunchKernelGGL((rx_demod_kernel<N, 2, 1, 3, DF_FOUR_PER_LANE>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
+                hipLaunchKernelGGL((rx_demod_kernel<N, 2, 1, 3, PLAIN>), dim3(grid), dim3(DG::WG), lds, s, rx, a);
             return hipGetLastError();
         }
         if (a.variant != 0 && a.variant < 100 && bmode == 1 && a.mod == 4) {
@@ -716,7 +725,9 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         hipLaunchKernelGGL((rx_demod_kernel<N, 4, 1, MW, FL>), dim3(grid), dim3(DG::WG), LDSB, s, rx, a);                   \
         return hipGetLastError();                                                                                           \
     }
-            OFDM_LV(1, 3, DF_NT, lds)
+            OFDM_LV(1, 3, DF_TEMPORAL_LD | DF_TEMPORAL_ST, lds)
+            OFDM_LV(14, 3, DF_TEMPORAL_ST, lds)                      // non-temporal loads only
+            OFDM_LV(15, 3, DF_TEMPORAL_LD, lds)                      // non-temporal stores only
             OFDM_LV(2, 3, DF_GAINS_GLOBAL, DG::lds_bytes(rx.Kd, false))
             OFDM_LV(3, 3, DF_GENERIC_BITS, lds)
             OFDM_LV(5, 3, DF_NO_PIPE, lds)
@@ -726,7 +737,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
             OFDM_LV(10, 3, DF_LANE_TWIDDLES | DF_PSUM_READBACK, lds) // the round-1 kernel
             OFDM_LV(11, 3, DF_PSUM_READBACK, lds)
             OFDM_LV(12, 3, DF_LANE_TWIDDLES, lds)
-            OFDM_LV(13, 3, DF_FOUR_PER_LANE, lds)                    // round-1 output mapping
+            OFDM_LV(13, 3, DF_FOUR_PER_LANE | DF_TEMPORAL_LD | DF_TEMPORAL_ST, lds)   // round-1 output mapping, plain accesses
 #undef OFDM_LV
         }
     }
