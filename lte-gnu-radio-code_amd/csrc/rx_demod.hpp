@@ -589,11 +589,24 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                             const cf z[2] = {cmul(cf{av.x, av.y} * scale, cf{g.x, g.y}), cmul(cf{av.z, av.w} * scale, cf{g.z, g.w})};
                             if (a.eq) {
                                 const float4 o4 = float4{z[0].x, z[0].y, z[1].x, z[1].y};
+                                typedef float f4 __attribute__((ext_vector_type(4)));
+                                [[maybe_unused]] const f4 ov = f4{o4.x, o4.y, o4.z, o4.w};
+                                [[maybe_unused]] cf* op = a.eq + orow * Kd_ + idx;
+#ifdef OFDM_EXPERIMENTS
+                                // cache-policy study of the output store (FLAGS bits 12-13): sc1 / sc0 sc1 / sc0 sc1 nt
+                                constexpr unsigned SPOL = (FLAGS >> 12) & 3u;
+                                if constexpr (SPOL == 1) {
+                                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(op), "v"(ov) : "memory");
+                                } else if constexpr (SPOL == 2) {
+                                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(op), "v"(ov) : "memory");
+                                } else if constexpr (SPOL == 3) {
+                                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(op), "v"(ov) : "memory");
+                                } else
+#endif
                                 if constexpr (NT) {
-                                    typedef float f4 __attribute__((ext_vector_type(4)));
-                                    __builtin_nontemporal_store(f4{o4.x, o4.y, o4.z, o4.w}, reinterpret_cast<f4*>(a.eq + orow * Kd_ + idx));
+                                    __builtin_nontemporal_store(ov, reinterpret_cast<f4*>(op));
                                 } else {
-                                    *reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx) = o4;
+                                    *reinterpret_cast<float4*>(op) = o4;
                                 }
                             }
                             if constexpr (BMODE == 1) wp[hx] = pack2<MOD, ASMB>(z);
@@ -727,6 +740,9 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     }
             OFDM_LV(1, 3, DF_TEMPORAL_LD | DF_TEMPORAL_ST, lds)
             OFDM_LV(14, 3, DF_TEMPORAL_ST, lds)                      // non-temporal loads only
+            OFDM_LV(21, 3, 1u << 12, lds)                            // output stores with sc1
+            OFDM_LV(22, 3, 2u << 12, lds)                            // ... sc0 sc1
+            OFDM_LV(23, 3, 3u << 12, lds)                            // ... sc0 sc1 nt
             OFDM_LV(15, 3, DF_TEMPORAL_LD, lds)                      // non-temporal stores only
             OFDM_LV(2, 3, DF_GAINS_GLOBAL, DG::lds_bytes(rx.Kd, false))
             OFDM_LV(3, 3, DF_GENERIC_BITS, lds)
