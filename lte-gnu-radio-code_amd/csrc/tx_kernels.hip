@@ -248,8 +248,11 @@ __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, floa
                     q[u].x *= scale;
                     q[u].y *= scale;
                     q[u].z *= scale;
-                    q[u].w *= scale;
-                    if (j < half) o4[j] = q[u];
+                        q[u].w *= scale;
+                    if (j < half) {
+                        typedef float f4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(f4{q[u].x, q[u].y, q[u].z, q[u].w}, reinterpret_cast<f4*>(o4 + j));   // streamed out once
+                    }
                 }
             }
         } else {
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(256) channel_kernel(ChanArgs a) {
             acc1.y += r1 * __builtin_amdgcn_sinf(u1);
         }
         if (wide && n + 1 < a.out_len) {
-            *reinterpret_cast<float4*>(out + n) = float4{acc0.x, acc0.y, acc1.x, acc1.y};
+            *reinterpret_cast<float4*>(out + n) = float4{acc0.x, acc0.y, acc1.x, acc1.y};   // (a non-temporal hint here: 8 % slower)
         } else {
             out[n] = acc0;
             if (n + 1 < a.out_len) out[n + 1] = acc1;
