@@ -450,3 +450,43 @@ def test_count_bit_errors_equals_numpy(om, n, off_a, off_b):
     om.count_bit_errors(da.data_ptr() + off_a, db.data_ptr() + off_b, n, cnt.data_ptr())
     torch.cuda.synchronize()
     assert int(cnt.item()) == 2 * want
+
+
+@pytest.mark.parametrize("N,cp,Ks,Kd,mod", [(1024, 72, 1022, 602, "QPSK"), (2048, 144, 2046, 1198, "16QAM"), (4096, 288, 4094, 2402, "64QAM"),
+                                             (1024, 72, 1024, 1024, "16QAM")])
+def test_dense_output_mapping_on_awkward_bin_counts(om, N, cp, Ks, Kd, mod):
+    """From 1024-pt up a lane of the demod kernel owns two PAIRS of list entries 128 apart and bits leave in groups of four
+    entries assembled across a lane pair.  Bin counts that are even but not a multiple of 4 (the last pair of a row has no
+    partner: equalised symbols and one-bit-per-byte output only -- packed output is refused for them, as before), and K == N
+    (bin N/2 listed twice, every list entry used), against the fp64 oracle."""
+    n_sym, n_frames = 8, 2
+    L = N + cp
+    bps = orc.BITS_PER_SYMBOL[mod]
+    rng = np.random.default_rng(Kd)
+    nb = (n_sym // 4) * 3 * Kd * bps
+    iq = np.zeros((n_frames, n_sym * L + cp + 3), np.complex64)
+    for f in range(n_frames):
+        tx = orc.tx_modulate(rng.integers(0, 2, nb), N, cp, Ks, Kd, n_sym, modulation=mod)
+        iq[f] = orc.channel_apply(tx, orc.REF_TAPS, N)[:iq.shape[1]]
+    fl = iq.shape[1]
+    rx = om.RxEngine(n_sym, N, cp, Ks, (1, 3), Kd, 100, 0.7, modulation=mod)
+    nds = rx.data_symbols_per_frame(fl)
+    d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+    d_eq = om.DeviceBuffer(n_frames * nds * Kd * 8)
+    d_bu = om.DeviceBuffer(n_frames * nds * Kd * bps)
+    assert rx.demod_frames(d_iq, n_frames, fl, fl, d_eq, d_bu, om.BITS_UNPACKED, None) == nds
+    eq = d_eq.download(np.complex64, n_frames * nds * Kd).reshape(n_frames, nds, Kd)
+    bu = d_bu.download(np.uint8, n_frames * nds * Kd * bps).reshape(n_frames, -1)
+    rows = [r for r in range(n_sym) if r % 4 != 3]
+    for f in range(n_frames):
+        o = orc.RxOracle(n_sym, N, cp, Ks, [1, 3], Kd, 100, 0.7, force_fp64=True)
+        o.work(iq[f], np.zeros(fl, np.complex64))
+        assert_close(eq[f], o.est_data_freq[rows], "frame %d" % f)
+        assert np.array_equal(bu[f], orc.demap_hard(eq[f].ravel(), mod))
+    if Kd % 4 == 0:
+        d_bp = om.DeviceBuffer(n_frames * nds * Kd * bps // 8)
+        rx.demod_frames(d_iq, n_frames, fl, fl, None, d_bp, om.BITS_PACKED, None)
+        assert np.array_equal(np.unpackbits(d_bp.download(np.uint8, n_frames * nds * Kd * bps // 8)), bu.ravel())
+    else:
+        with pytest.raises(ValueError):
+            rx.demod_frames(d_iq, n_frames, fl, fl, None, om.DeviceBuffer(n_frames * nds * Kd * bps // 8 + 8), om.BITS_PACKED, None)
