@@ -548,12 +548,11 @@ __global__ void __launch_bounds__(256) probe_kernel(const float4* __restrict__ i
         for (int64_t s = blockIdx.x; s < n_sym; s += gridDim.x) {
             const float4* src = in + s * (sym_in16 + gap16) + gap16;
             float4* dst = out + s * sym_out16;
-            float4 acc = float4{0.f, 0.f, 0.f, 0.f};
-            for (int i = threadIdx.x; i < sym_in16; i += blockDim.x) {
-                const float4 v = src[i];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            for (int i = threadIdx.x; i < sym_out16; i += blockDim.x) dst[i] = acc;
+            // the same cache policy as the demod kernel's streams (non-temporal loads and stores)
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            for (int i = threadIdx.x; i < sym_in16; i += blockDim.x) acc += __builtin_nontemporal_load(reinterpret_cast<const f4*>(src) + i);
+            for (int i = threadIdx.x; i < sym_out16; i += blockDim.x) __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(dst) + i);
         }
     }
 }
