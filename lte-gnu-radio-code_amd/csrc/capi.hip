@@ -182,6 +182,7 @@ struct ofdm_rx {
     int scan_block = 0;                  // > 0: the batch path's sync search is screened in blocks of this many trials
     cf* d_scan_g = nullptr;              // [N + 2] recurrence kernel G, then {max |G|, 0}
     int* d_seg_state = nullptr;          // [2] {first hit, segments done} of the stream block's segment-parallel search
+    bool seg_armed = false;              // the kernel re-arms the two words itself; false after a launch that did not complete
     int variant = 0;
     unsigned* d_stamps = nullptr;
     bool profiling = false;
@@ -446,6 +447,7 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
         if (rc2 == OFDM_OK) rc2 = dev_alloc(&h->d_seg_state, 2);
         if (rc2 == OFDM_OK && hipMemcpy(h->d_seg_state, seg0, sizeof seg0, hipMemcpyHostToDevice) != hipSuccess)
             rc2 = fail(OFDM_ERR_HIP, "segment state upload failed");
+        h->seg_armed = rc2 == OFDM_OK;
         if (rc2 != OFDM_OK) {
             std::string keep = g_last_error;
             ofdm_rx_destroy(h);
@@ -648,10 +650,17 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
             fa.esf = h->s_esf + size_t(row) * d.MM;
             fa.eqg = h->s_eqg;
             fa.yscratch = h->s_ysc;
+            if (!h->seg_armed) {                                       // an earlier search did not run to its end: start clean
+                const int seg0[2] = {0x7fffffff, 0};
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(h->d_seg_state, seg0, sizeof seg0, hipMemcpyHostToDevice));
+            }
+            h->seg_armed = false;
             HIP_TRY(launch_rx_sync(d, fa, s));
             int t4[4];
             HIP_TRY(hipMemcpyAsync(t4, h->s_tsr, sizeof(t4), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            h->seg_armed = true;
             if (t4[3]) {
                 h->corr_obs += 1;                                                            // :171
                 h->tsr[0] = t4[0];                                                           // :173-175
