@@ -44,6 +44,15 @@ print("ok", _lib.hip_runtime_path)
 
 @pytest.mark.parametrize("code", [LIB_FIRST, TORCH_FIRST], ids=["library-first", "torch-first"])
 def test_either_import_order_works(code):
-    r = subprocess.run([sys.executable, "-c", code % (ROOT, PKG)], capture_output=True, text=True, timeout=300)
+    # One fresh interpreter per order.  Seen once in ~25 suite runs on the GPU pool: the library-first child did not come back
+    # within 300 s on a fresh box (never reproduced; the same child takes 6 s).  A child that overruns 120 s is killed and the
+    # order is tried once more, so that a stuck box start-up does not read as an import-order failure; a second overrun fails.
+    for attempt in (1, 2):
+        try:
+            r = subprocess.run([sys.executable, "-c", code % (ROOT, PKG)], capture_output=True, text=True, timeout=120)
+            break
+        except subprocess.TimeoutExpired:
+            if attempt == 2:
+                raise
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     assert "torch/lib/libamdhip64" in r.stdout          # torch is installed here: its bundled runtime is the shared one
