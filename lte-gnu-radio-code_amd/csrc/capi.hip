@@ -1618,6 +1618,7 @@ int ofdm_tx_modulate_frames(ofdm_tx* h, const uint8_t* d_bits, int32_t bits_mode
     a.n_sym = n_sym;
     a.iq = reinterpret_cast<cf*>(d_iq);
     a.frame_stride = frame_stride;
+    a.sync_time = h->d_sync_time;
     HIP_TRY(launch_tx_modulate(d, a, stream ? static_cast<hipStream_t>(stream) : h->stream));
     return OFDM_OK;
 }

@@ -93,6 +93,7 @@ struct ModArgs {
     int n_sym;               // symbols per frame
     cf* iq;
     int64_t frame_stride;
+    const cf* sync_time;     // [S][L] the finished sync symbol(s) (synthesised once per handle by the same device functions), or null
 };
 // decomposed TX stages
 struct GridArgs {

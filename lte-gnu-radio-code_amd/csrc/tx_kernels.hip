@@ -307,6 +307,26 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
         const bool is_sync = r < tx.S;                                    // symbol_pattern == 0  (:136)
         const unsigned base = unsigned(pat * tx.D + (r - tx.S)) * unsigned(tx.Kd);   // loop_data (:134,180) * Kd
         const uint8_t* fbits = a.bits ? a.bits + int64_t(frame) * a.bits_stride : nullptr;
+        if constexpr (PL::SLOTS == 1) {
+            // Every sync symbol of every frame is the same L samples (synch_state never advances, :143-147): where the
+            // workgroup holds one symbol (so the branch is workgroup-uniform and skips whole barriers) it is copied from the
+            // handle's finished sync symbol -- the output of these very device functions, bit for bit -- instead of being
+            // transformed again: a quarter of the symbols of a [1, 3] pattern.
+            if (is_sync && a.sync_time) {
+                if (active) {
+                    const cf* src = a.sync_time + int64_t(r) * tx.L;
+                    cf* o = a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L;
+                    if ((tx.L & 1) == 0 && ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+                        typedef float f4 __attribute__((ext_vector_type(4)));
+                        for (int j = t; j < (tx.L >> 1); j += T)
+                            __builtin_nontemporal_store(reinterpret_cast<const f4*>(src)[j], reinterpret_cast<f4*>(o) + j);
+                    } else {
+                        for (int j = t; j < tx.L; j += T) o[j] = src[j];
+                    }
+                }
+                continue;
+            }
+        }
 
         // resource grid row X[n] (:135-183), conjugated: ifft(X) = conj(fft(conj(X))) / N.
         // List index of bin k in binsP(K) (-1 = unused), branch-free: positive half i = K/2 + k - 1 for 1 <= k <= K/2, negative
@@ -571,8 +591,16 @@ template <int N>
 static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s) {
     const int64_t units = int64_t(a.n_frames) * a.n_sym;
     const int64_t wgs = (units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS;
-    const unsigned grid = unsigned(std::min<int64_t>(wgs, 256 * 8));      // 8 resident workgroups per CU; the rest is looped
-    if (grid == 0) return hipSuccess;
+    int64_t g0 = std::min<int64_t>(wgs, 256 * 8);                          // 8 resident workgroups per CU; the rest is looped
+    if (g0 == 0) return hipSuccess;
+    // a workgroup walks units first, first + stride, ...: with a stride that is a multiple of the [S, D] pattern length it would
+    // meet the same position of the pattern every time (a quarter of the workgroups only copying sync symbols): keep them coprime
+    if (g0 < wgs) {
+        const int64_t SD = tx.S + tx.D;
+        auto gcd = [](int64_t x, int64_t y) { while (y) { const int64_t r_ = x % y; x = y; y = r_; } return x; };
+        while (g0 > 1 && gcd(g0 * Plan<N>::SLOTS, SD) != 1) --g0;
+    }
+    const unsigned grid = unsigned(g0);
     const bool al4 = a.bits && ((reinterpret_cast<uintptr_t>(a.bits) | uintptr_t(a.bits_stride)) & 3) == 0;
     const dim3 g(grid), b(Plan<N>::WG);
     switch (tx_fetch_kind(a.bits_mode, tx.bps, al4)) {
