@@ -193,3 +193,26 @@ def test_fused_modulator_layout_fallbacks_equal_the_oracle(om, N, cp, Kd, mod):
     y1 = np.stack([o[1 + f * stride:1 + f * stride + n_sym * L] for f in range(n_frames)])
     assert np.array_equal(y1, y0)
     assert o[0] == 0 and all(o[1 + f * stride + n_sym * L] == 0 for f in range(n_frames))     # nothing written outside the frames
+
+
+@pytest.mark.parametrize("N,cp,Kd,S,D,n_sym", [(1024, 72, 600, 2, 3, 15), (64, 16, 60, 2, 3, 10), (2048, 144, 1200, 1, 2, 9), (4096, 288, 2400, 3, 1, 8)])
+def test_fused_modulator_with_other_sync_patterns(om, N, cp, Kd, S, D, n_sym):
+    """[S, D] patterns other than [1, 3], incl. S > 1 (every sync symbol carries ZC segment 0: the reference never advances
+    `synch_state`, MultiAntennaSystem.py:143-147).  From 1024-pt up the kernel copies sync symbols from the handle's finished
+    ones, row r of [S][L] for the r-th sync symbol of a pattern, and its grid stride is kept coprime with S + D."""
+    n_frames = 3
+    rng = np.random.default_rng(N + S)
+    tx = om.TxEngine(N, cp, N - 2, Kd, (S, D), "QPSK")
+    nb = tx.bits_per_frame(n_sym)
+    bits = rng.integers(0, 2, (n_frames, nb)).astype(np.uint8)
+    ref = np.stack([orc.tx_modulate(bits[f], N, cp, N - 2, Kd, n_sym, synch_dat=(S, D)) for f in range(n_frames)])
+    d_bits = om.DeviceBuffer(bits.nbytes).upload(bits)
+    d_iq = om.DeviceBuffer(ref.size * 8)
+    tx.modulate_frames(d_bits, n_frames, n_sym, d_iq)
+    y = d_iq.download(np.complex64, ref.size).reshape(ref.shape)
+    assert relerr(y, ref) < TOL
+    L = N + cp
+    sync = tx.sync_symbol()
+    for s in range(n_sym):
+        if s % (S + D) < S:
+            assert np.array_equal(y[0, s * L:(s + 1) * L], sync[s % (S + D)])
