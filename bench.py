@@ -338,7 +338,16 @@ def main(argv=None):
     # BENCH_REHEARSAL=1: rehearse the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices, the
     # all-gather goes through gloo on host copies).  Never used for reported numbers.
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
-    if world > 1:
+    # BENCH_FORCE_DIST=1 with one rank: a one-rank RCCL group runs every collective of the N > 1 path (init, asynchronous
+    # all_gather_into_tensor on the launch stream, waits, all_reduce, barrier) -- the only way to execute those calls on a box
+    # with one GPU (RCCL refuses two ranks on one device).  The line it prints is not a measurement of anything.
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    multi = world > 1 or force_dist
+    if force_dist:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -348,7 +357,19 @@ def main(argv=None):
             if torch.cuda.device_count() < world:
                 raise SystemExit("WORLD_SIZE=%d but %d GPU(s) visible" % (world, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON line, so
+            # file descriptor 1 points at stderr until the communicator exists
+            sys.stdout.flush()
+            fd1 = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(fd1, 1)
+                os.close(fd1)
     else:
         torch.cuda.set_device(0)
     device = torch.cuda.current_device()
@@ -384,7 +405,7 @@ def main(argv=None):
     bytes_per_frame_bits = nds * Kd * bps // 8
     d_eq = None if args.no_eq else torch.empty((n_frames, nds, Kd, 2), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    per_batch = args.chunks if (world > 1 and batches == 1) else 1
+    per_batch = args.chunks if (multi and batches == 1) else 1
     bounds = []
     for b in range(batches):                     # rows of the step's bit buffer: batch-major, frames within
         bounds += [(b * n_frames + f0, b * n_frames + f1) for f0, f1 in od.sub_batches(n_frames, per_batch)]
@@ -394,7 +415,7 @@ def main(argv=None):
     # generation is enough -- the gather of batch b has the other batches' demod time before its buffers come round again.
     pipe = od.GatherPipeline(dist, torch, world, bounds, n_frames * batches, bytes_per_frame_bits, "cuda",
                              recv_device="cpu" if rehearsal else "cuda", host_staging=rehearsal,
-                             generations=1 if batches > 1 else 2)
+                             generations=1 if batches > 1 else 2, gather_at_world_1=force_dist)
 
     def produce(bits, r0, r1):
         b, f0 = divmod(r0, n_frames)
@@ -446,7 +467,7 @@ def main(argv=None):
         else:                                 # a lead pushes the last pattern out of the frame: compare the patterns that fit
             keep = (len(rxb) // (n_sym // 4)) * ((fl - lead0) // (4 * L))
             ber = float(np.unpackbits(rxb[:keep] ^ txb[:keep]).sum()) / max(keep * 8, 1)
-    if world > 1:
+    if multi:
         assert torch.equal(od.reassemble(torch, gathered, world)[rank].cpu(), d_bits.cpu()), "all-gather did not reassemble this rank's own shard"
         # one all-gather of a sub-batch on its own (untimed extra): what the fabric gives without demod traffic beside it
         f0, f1 = bounds[0]

@@ -48,13 +48,16 @@ class GatherPipeline:
     With world == 1 nothing is gathered (one generation, `produce` only).  `host_staging` gathers host copies of the rows
     (gloo rehearsal of the control flow on a box with fewer GPUs than ranks)."""
 
-    def __init__(self, dist, torch, world, bounds, n_rows, row_bytes, device, recv_device=None, generations=2, host_staging=False):
+    def __init__(self, dist, torch, world, bounds, n_rows, row_bytes, device, recv_device=None, generations=2, host_staging=False,
+                 gather_at_world_1=False):
         self.dist, self.torch, self.world, self.bounds = dist, torch, world, list(bounds)
-        self.gen = generations if world > 1 else 1
+        # a one-rank group still runs the collectives when asked to (the only way to exercise the RCCL calls on a 1-GPU box)
+        self.gather = world > 1 or (gather_at_world_1 and dist is not None)
+        self.gen = generations if self.gather else 1
         self.host_staging = host_staging
         self.bits = [torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=device) for _ in range(self.gen)]
         self.recv = None
-        if world > 1:
+        if self.gather:
             self.recv = [alloc_gather_buffers(torch, world, self.bounds, row_bytes, recv_device or device) for _ in range(self.gen)]
         self.pending = [[None] * len(self.bounds) for _ in range(self.gen)]
         self.steps = 0
@@ -68,7 +71,7 @@ class GatherPipeline:
                 self.pending[g][ci].wait()          # stream-ordered: the gather that read bits[f0:f1] `generations` steps ago
                 self.pending[g][ci] = None
             produce(bits, f0, f1)
-            if self.world > 1:
+            if self.gather:
                 src = bits[f0:f1].cpu() if self.host_staging else bits[f0:f1].contiguous()
                 self.pending[g][ci] = self.dist.all_gather_into_tensor(self.recv[g][ci], src, async_op=True)
         self.steps += 1
