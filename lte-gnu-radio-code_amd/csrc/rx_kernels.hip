@@ -826,11 +826,49 @@ hipError_t launch_bit_errors(const uint8_t* a, const uint8_t* b, int64_t n, unsi
 }
 
 // ------------------------------------------------------------------------------------------ standalone de-mapper
-__global__ void demap_hard_kernel(DemapArgs a) {
-    const int64_t n = a.n;
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const unsigned hb = hard_bits_rt(a.sym[i], a.mod);
-        for (int b = 0; b < a.mod; ++b) a.hard[i * a.mod + b] = (hb >> (a.mod - 1 - b)) & 1u;
+// Hard bits, one per byte.  A thread takes FOUR consecutive symbols (two 16 B loads) and writes their 4*MOD bytes as whole
+// words (byte-by-byte stores, one symbol per thread, ran at 0.36-0.64 of the HBM rate); the last n % 4 symbols and buffers that
+// are not 16-byte aligned take the plain path.
+template <int MOD>
+__device__ __forceinline__ void demap_hard_words(const cf (&z)[4], uint32_t (&w)[MOD]) {
+#pragma unroll
+    for (int k = 0; k < MOD; ++k) w[k] = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned hb = hard_bits<MOD>(z[e]);
+#pragma unroll
+        for (int j = 0; j < MOD; ++j) {
+            const int k = e * MOD + j;                                 // byte index in the group's 4*MOD bytes
+            w[k >> 2] |= ((hb >> (MOD - 1 - j)) & 1u) << (8 * (k & 3));
+        }
+    }
+}
+template <int MOD>
+__global__ void __launch_bounds__(256) demap_hard_kernel(DemapArgs a) {
+    const int64_t n = a.n, n4 = n >> 2;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a.sym) | reinterpret_cast<uintptr_t>(a.hard)) & 15) == 0;
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+    if (wide) {
+        for (int64_t g = gid; g < n4; g += stride) {
+            const float4 v0 = reinterpret_cast<const float4*>(a.sym)[2 * g], v1 = reinterpret_cast<const float4*>(a.sym)[2 * g + 1];
+            const cf z[4] = {cf{v0.x, v0.y}, cf{v0.z, v0.w}, cf{v1.x, v1.y}, cf{v1.z, v1.w}};
+            uint32_t w[MOD];
+            demap_hard_words<MOD>(z, w);
+            uint32_t* o = reinterpret_cast<uint32_t*>(a.hard + g * 4 * MOD);
+            if constexpr (MOD == 4) {
+                *reinterpret_cast<uint4*>(o) = uint4{w[0], w[1], w[2], w[3]};
+            } else if constexpr (MOD == 1) {
+                o[0] = w[0];
+            } else {                                                   // 8 or 24 bytes, 8-byte aligned
+#pragma unroll
+                for (int k = 0; k < MOD; k += 2) *reinterpret_cast<uint2*>(o + k) = uint2{w[k], w[k + 1]};
+            }
+        }
+    }
+    for (int64_t i = (wide ? n4 * 4 : 0) + gid; i < n; i += stride) {
+        const unsigned hb = hard_bits<MOD>(a.sym[i]);
+#pragma unroll
+        for (int b = 0; b < MOD; ++b) a.hard[i * MOD + b] = uint8_t((hb >> (MOD - 1 - b)) & 1u);
     }
 }
 
@@ -858,7 +896,8 @@ __global__ void __launch_bounds__(256) demap_dmin_kernel(DemapArgs a) {
         if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0];
+    // more workgroups than partial slots (256 of them cannot keep the memory system busy): the slots are zeroed by the launcher
+    if (threadIdx.x == 0) atomicAdd(a.partial + (blockIdx.x % DEMAP_PARTIALS), sh[0]);
 }
 
 // pass 2: llrp0 / llrp1 (BitRecovery.py:102-125)
@@ -873,19 +912,39 @@ __global__ void __launch_bounds__(256) demap_soft_kernel(DemapArgs a) {
     const double sigma = 0.7071067811865476 * (sh_tot / double(a.n));                    // :102
     const float hf = float(-0.5 / (sigma * sigma));                                      // -0.5*dfact :103
     constexpr float K = 1.414213562373095f;                                              // :57
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+    auto metrics = [&](cf z, float (&m0)[2], float (&m1)[2]) {
         bool rp, ip;
         cf e;
-        qpsk_nearest(a.sym[i], rp, ip, e);
+        qpsk_nearest(z, rp, ip, e);
         const float nr = hf * fabsf(e.x), fr = hf * (K - fabsf(e.x));
         const float ni = hf * fabsf(e.y), fi = hf * (K - fabsf(e.y));
+        m0[0] = rp ? nr : fr;
+        m0[1] = ip ? ni : fi;
+        m1[0] = rp ? fr : nr;
+        m1[1] = ip ? fi : ni;
+    };
+    // two symbols per thread: one 16 B load, one 16 B store per metric array (buffers 16-byte aligned; else one by one)
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a.sym) | reinterpret_cast<uintptr_t>(a.soft0) | reinterpret_cast<uintptr_t>(a.soft1)) & 15) == 0;
+    const int64_t n2 = wide ? a.n >> 1 : 0;
+    for (int64_t g = gid; g < n2; g += stride) {
+        const float4 v = reinterpret_cast<const float4*>(a.sym)[g];
+        float a0[2], a1[2], b0[2], b1[2];
+        metrics(cf{v.x, v.y}, a0, a1);
+        metrics(cf{v.z, v.w}, b0, b1);
+        if (a.soft0) reinterpret_cast<float4*>(a.soft0)[g] = float4{a0[0], a0[1], b0[0], b0[1]};
+        if (a.soft1) reinterpret_cast<float4*>(a.soft1)[g] = float4{a1[0], a1[1], b1[0], b1[1]};
+    }
+    for (int64_t i = n2 * 2 + gid; i < a.n; i += stride) {
+        float m0[2], m1[2];
+        metrics(a.sym[i], m0, m1);
         if (a.soft0) {
-            a.soft0[2 * i] = rp ? nr : fr;
-            a.soft0[2 * i + 1] = ip ? ni : fi;
+            a.soft0[2 * i] = m0[0];
+            a.soft0[2 * i + 1] = m0[1];
         }
         if (a.soft1) {
-            a.soft1[2 * i] = rp ? fr : nr;
-            a.soft1[2 * i + 1] = ip ? fi : ni;
+            a.soft1[2 * i] = m1[0];
+            a.soft1[2 * i + 1] = m1[1];
         }
     }
 }
@@ -944,7 +1003,8 @@ __global__ void __launch_bounds__(256) demap_dmin_qam_kernel(DemapArgs a) {
         if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = sh[0];
+    // more workgroups than partial slots (256 of them cannot keep the memory system busy): the slots are zeroed by the launcher
+    if (threadIdx.x == 0) atomicAdd(a.partial + (blockIdx.x % DEMAP_PARTIALS), sh[0]);
 }
 
 template <int BPS>
@@ -959,6 +1019,7 @@ __global__ void __launch_bounds__(256) demap_soft_qam_kernel(DemapArgs a) {
     const double sigma = 0.7071067811865476 * (sh_tot / double(a.n));
     const float hf = float(-0.5 / (sigma * sigma));
     constexpr int NB = Pam<BPS>::NB;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a.soft0) | reinterpret_cast<uintptr_t>(a.soft1)) & 15) == 0;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
         const cf z = a.sym[i];
         float r0[NB], r1[NB], i0[NB], i1[NB], e;
@@ -972,11 +1033,16 @@ __global__ void __launch_bounds__(256) demap_soft_qam_kernel(DemapArgs a) {
             o1[2 * j] = hf * r1[j];
             o1[2 * j + 1] = hf * i1[j];
         }
-        // BPS floats per symbol = 16 B (16-QAM) / 24 B (64-QAM), 8-byte aligned: float2 stores
+        // BPS floats per symbol = 16 B (16-QAM: one 16 B store where the buffer allows it) / 24 B (64-QAM: three 8 B stores)
+        if (BPS == 4 && wide) {
+            if (a.soft0) *reinterpret_cast<float4*>(a.soft0 + i * BPS) = float4{o0[0], o0[1], o0[2], o0[3]};
+            if (a.soft1) *reinterpret_cast<float4*>(a.soft1 + i * BPS) = float4{o1[0], o1[1], o1[2], o1[3]};
+        } else {
 #pragma unroll
-        for (int b = 0; b < BPS; b += 2) {
-            if (a.soft0) *reinterpret_cast<float2*>(a.soft0 + i * BPS + b) = make_float2(o0[b], o0[b + 1]);
-            if (a.soft1) *reinterpret_cast<float2*>(a.soft1 + i * BPS + b) = make_float2(o1[b], o1[b + 1]);
+            for (int b = 0; b < BPS; b += 2) {
+                if (a.soft0) *reinterpret_cast<float2*>(a.soft0 + i * BPS + b) = make_float2(o0[b], o0[b + 1]);
+                if (a.soft1) *reinterpret_cast<float2*>(a.soft1 + i * BPS + b) = make_float2(o1[b], o1[b + 1]);
+            }
         }
     }
 }
@@ -1147,20 +1213,31 @@ hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int 
 
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 2048));
-    if (a.hard) hipLaunchKernelGGL(demap_hard_kernel, dim3(grid), dim3(256), 0, s, a);
+    const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 4096));
+    if (a.hard) {
+        const unsigned gh = unsigned(std::min<int64_t>((a.n / 4 + 255) / 256 + 1, 4096));
+        switch (a.mod) {
+            case 1: hipLaunchKernelGGL(demap_hard_kernel<1>, dim3(gh), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(demap_hard_kernel<2>, dim3(gh), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL(demap_hard_kernel<4>, dim3(gh), dim3(256), 0, s, a); break;
+            case 6: hipLaunchKernelGGL(demap_hard_kernel<6>, dim3(gh), dim3(256), 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (a.soft0 || a.soft1) {
+        if (a.mod != 2 && a.mod != 4 && a.mod != 6) return hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(a.partial, 0, DEMAP_PARTIALS * sizeof(double), s);
+        if (e != hipSuccess) return e;
+        const unsigned gd = unsigned(std::min<int64_t>((a.n + 255) / 256, 2048));
         if (a.mod == 2) {
-            hipLaunchKernelGGL(demap_dmin_kernel, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_dmin_kernel, dim3(gd), dim3(256), 0, s, a);
             hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
         } else if (a.mod == 4) {
-            hipLaunchKernelGGL(demap_dmin_qam_kernel<4>, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_dmin_qam_kernel<4>, dim3(gd), dim3(256), 0, s, a);
             hipLaunchKernelGGL(demap_soft_qam_kernel<4>, dim3(grid), dim3(256), 0, s, a);
-        } else if (a.mod == 6) {
-            hipLaunchKernelGGL(demap_dmin_qam_kernel<6>, dim3(DEMAP_PARTIALS), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(demap_soft_qam_kernel<6>, dim3(grid), dim3(256), 0, s, a);
         } else {
-            return hipErrorInvalidValue;
+            hipLaunchKernelGGL(demap_dmin_qam_kernel<6>, dim3(gd), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_soft_qam_kernel<6>, dim3(grid), dim3(256), 0, s, a);
         }
     }
     return hipGetLastError();
