@@ -143,15 +143,21 @@ def _profiled():
     return "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
 
 
-def cpu_baseline(cfg, iq_host):
-    """oracle/cpu_baseline.py in a fresh child process (no GPU state) on a bounded sample of this workload."""
+def cpu_baseline(cfg, d_rx, fl):
+    """oracle/cpu_baseline.py in a fresh child process (no GPU state) on a bounded sample of this workload: whole frames of the
+    batch that was just timed, >= 8 per usable host core for the vectorised leg (oracle/cpu_baseline.py names its three legs)."""
     import tempfile
+    from oracle import cpu_baseline as cb
+    n = min(int(d_rx.shape[0]), cb.sample_frames_wanted())
+    iq_host = d_rx[:n].cpu().numpy().view(np.complex64).reshape(n, fl)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "sample.npy")
         np.save(path, iq_host)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), path,
-                            json.dumps({k: cfg[k] for k in ("nfft", "cp", "Kd", "snr_db")})],
-                           capture_output=True, text=True, timeout=600, env=_clean_env())
+        del iq_host
+        keys = {k: cfg[k] for k in ("nfft", "cp", "Kd", "snr_db")}
+        keys["gate"] = cfg.get("gate", 0.7)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), path, json.dumps(keys)],
+                           capture_output=True, text=True, timeout=900, env=_clean_env())
     if r.returncode != 0:
         raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -393,6 +399,21 @@ def main(argv=None):
     fl = n_sym * L
     bps = BPS[mod]
 
+    # Pre-flight: the whole plan is resident at once (cfg4 at N = 8: 147 GB IQ + 7.5 GB equalised symbols + 5.7 GB bits + 45 GB
+    # receive buffer = 205 GB of the 288).  Check it against what the device reports free BEFORE the first allocation, loudly.
+    nds_plan = (n_sym // 4) * 3
+    bits_rows = n_frames * batches * (nds_plan * Kd * bps // 8)
+    gens = 1 if batches > 1 else 2
+    plan = dict(iq=batches * n_frames * fl * 8, tx_staging=min(256, n_frames) * fl * 8, tx_bits=bits_rows,
+                eq=0 if args.no_eq else n_frames * nds_plan * Kd * 8, bits=gens * bits_rows,
+                gather_recv=(gens * world * bits_rows) if (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1") else 0,
+                frame_state=n_frames * (2 * N + Kd) * 8 + n_frames * 16)
+    need = int(sum(plan.values()) * 1.02) + (1 << 30)          # 2 % allocator rounding + 1 GiB for the context, RCCL and probes
+    free_b, total_b = torch.cuda.mem_get_info()
+    if need > free_b:
+        raise SystemExit("bench.py --config %s --gpus %d: the resident plan needs %.1f GB per GPU (%s) but device %d reports %.1f GB free "
+                         "of %.1f GB.  Nothing was allocated." % (args.config, world, need / 1e9,
+                         ", ".join("%s %.1f" % (k, v / 1e9) for k, v in plan.items() if v), device, free_b / 1e9, total_b / 1e9))
     inputs = [build_inputs(torch, om, cfg, n_frames, device, seed=20260101 + rank + 1000 * b, lead=args.lead) for b in range(batches)]
     rxe = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, cfg["snr_db"], cfg.get("gate", 0.7), modulation=mod, device=device)
     rxe.reserve(n_frames)
@@ -436,8 +457,13 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rxe.set_profiling(True)                   # resets the library's event ring: only the timed steps are averaged
-    for _ in range(args.steps):
+    # one event per step boundary on the launch stream (torch's current stream IS the stream the C ABI launches on): the
+    # distribution of the step time (median, min: SURVEY 8(d)) beside the wall-clock mean that `value` is computed from
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     drain()                                   # every all-gather of the timed steps completes inside the timed region
     torch.cuda.synchronize()
     if dist is not None:
@@ -452,6 +478,7 @@ def main(argv=None):
 
     samples_per_step = world * batches * n_frames * fl
     ms_per_step = elapsed / args.steps * 1e3
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])      # rank 0's launch stream
     value = samples_per_step / (elapsed / args.steps) / 1e6
 
     # ---- correctness spot check of what was timed (rank 0): bit errors of frame 0 vs the transmitted bits
@@ -588,20 +615,21 @@ def main(argv=None):
                     package_power_w_and_sclk_mhz_under_load=power)
         cpu = None
         if world == 1 and not args.no_cpu:
-            iq_host = inputs[0][0][:16].cpu().numpy().view(np.complex64).reshape(16, fl)
-            cpu = cpu_baseline(cfg, iq_host)
+            cpu = cpu_baseline(cfg, inputs[0][0], fl)
         out = {
             "metric": METRIC,
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(float(np.median(step_ms)), 4), "ms_per_step_min": round(float(step_ms.min()), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "frames_per_gpu": n_frames * batches, "symbols_per_gpu": n_frames * batches * n_sym,
                        "samples_per_step": samples_per_step, "outputs": ("bits" if d_eq is None else "equalised symbols + packed bits"),
                        "parallelism": "frame-shard x%d%s" % (world, " + RCCL all-gather of packed bits (%d sub-batches per step, gathers overlapped with later demod launches)" % n_chunks if world > 1 else ""),
                        # stream-equivalent: every input sample counted at 8 B, although CP samples and 59 of 60 sync symbols per
                        # frame are never fetched (BASELINE.md's "HBM-read roofline" definition); roofline.physical_read_GBs is fetched bytes
                        "stream_equivalent_read_fraction_of_8TBs": round(value * 1e6 * 8 / world / 8e12, 4),
-                       "bit_error_rate_frame0": ber, "sync_search": sync_mode, "all_gather": gather_info},
+                       "bit_error_rate_frame0": ber, "sync_search": sync_mode, "all_gather": gather_info,
+                       "resident_plan_GB_per_gpu": round(need / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
     if dist is not None:

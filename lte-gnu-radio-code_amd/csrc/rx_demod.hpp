@@ -571,8 +571,28 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         const float scale = sqrtf(float(Kd_) / psum);                    // :233 p_est0
         stamp(5);                                                        // .. list read + power sum
 
-        if constexpr (DENSE) {
-            if (compute) {
+        // A pattern whose guard failed (:223) keeps the zero rows est_data_freq was created with (:88): in batch mode they are
+        // WRITTEN as zeros (and the bits as the de-map of 0+0j) at every FFT size and output mapping -- the branch sits outside
+        // the mapping split so that no instantiation can lose it.
+        if (!compute) {
+            if (sym_valid && a.zero_skipped) {
+                const cf zz[4] = {cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}};
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int idx = 4 * (t + T * q);
+                    if (idx < Kd_) {
+                        const bool four = idx + 2 < Kd_;
+                        if (a.eq) {
+                            float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx);
+                            o[0] = float4{0.f, 0.f, 0.f, 0.f};
+                            if (four) o[1] = float4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        if constexpr (BMODE != 0) store_bits<MOD, BMODE>(a.bits, orow * Kd_ + idx, zz, four ? 4 : 2);
+                    }
+                }
+            }
+        } else if constexpr (DENSE) {
+            {
                 const int wv = t >> 6, ln = t & 63;
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
@@ -626,7 +646,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                     }
                 }
             }
-        } else if (compute) {
+        } else {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int idx = 4 * (t + T * q);
@@ -654,21 +674,6 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                         }
                     }
                     if constexpr (BMODE != 0) store_bits<MOD, BMODE, ASMB>(a.bits, orow * Kd_ + idx, z, four ? 4 : 2);
-                }
-            }
-        } else if (sym_valid && a.zero_skipped) {                        // pattern guard failed: defined (zero) output
-            const cf zz[4] = {cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}};
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int idx = 4 * (t + T * q);
-                if (idx < Kd_) {
-                    const bool four = idx + 2 < Kd_;
-                    if (a.eq) {
-                        float4* o = reinterpret_cast<float4*>(a.eq + orow * Kd_ + idx);
-                        o[0] = float4{0.f, 0.f, 0.f, 0.f};
-                        if (four) o[1] = float4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    if constexpr (BMODE != 0) store_bits<MOD, BMODE>(a.bits, orow * Kd_ + idx, zz, four ? 4 : 2);
                 }
             }
         }

@@ -127,6 +127,14 @@ _lib = None
 hip_runtime_path = None     # the libamdhip64 this process ended up with (diagnostic)
 
 
+def _trace(what):
+    """OFDM_MI355X_TRACE_LOAD=1: one time-stamped line on stderr per step of load() (which dlopen a stuck start-up sits in)."""
+    if os.environ.get("OFDM_MI355X_TRACE_LOAD") == "1":
+        import sys
+        import time
+        print("[ofdm_mi355x.load %.3f] %s" % (time.time(), what), file=sys.stderr, flush=True)
+
+
 def _mapped_hip_runtimes():
     """Paths of every libamdhip64 mapped into this process (Linux)."""
     found = []
@@ -183,11 +191,14 @@ def load():
         raise OfdmLibraryError(
             "HIP library %s not found: build it with `make -C lte-gnu-radio-code_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    _trace("pinning the HIP runtime")
     _pin_hip_runtime()
+    _trace("HIP runtime: %s; dlopen %s" % (hip_runtime_path or "(system, via DT_NEEDED)", LIB_PATH))
     try:
         lib = C.CDLL(LIB_PATH)          # CDLL calls release the GIL (GNU Radio: one thread per block)
     except OSError as e:
         raise OfdmLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    _trace("library mapped")
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)

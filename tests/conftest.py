@@ -73,3 +73,10 @@ def assert_close(a, b, what=""):
     assert e1 < TOL_MAX and e2 < TOL_RMS and e3 < TOL_ELEM, "%s: max-norm %.3g (<%g), rms %.3g (<%g), element-wise %.3g (<%g)" % (
         what, e1, TOL_MAX, e2, TOL_RMS, e3, TOL_ELEM)
     return e1, e2, e3
+
+
+def poisoned(om, nbytes, device=0):
+    """Output buffer pre-filled with 0xFF (float NaN pattern / bit value 255): a row the kernel does not WRITE shows up as
+    poison instead of passing as whatever a fresh allocation happens to hold."""
+    nbytes = max(8, int(nbytes))
+    return om.DeviceBuffer(nbytes, device).upload(np.full(nbytes, 0xFF, np.uint8))

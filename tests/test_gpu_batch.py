@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import assert_close, relerr
+from conftest import assert_close, poisoned, relerr
 from oracle import ofdm_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -50,10 +50,10 @@ def test_batch_demod_vs_oracle(om, N, cp, Kd, mod, n_frames, n_sym):
     nds = rx.data_symbols_per_frame(frame_len)
     assert nds == (n_sym // 4) * 3
     d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
-    d_eq = om.DeviceBuffer(n_frames * nds * Kd * 8)
-    d_bp = om.DeviceBuffer(n_frames * nds * Kd * bps // 8)
-    d_bu = om.DeviceBuffer(n_frames * nds * Kd * bps)
-    d_tsr = om.DeviceBuffer(n_frames * 16)
+    d_eq = poisoned(om, n_frames * nds * Kd * 8)
+    d_bp = poisoned(om, n_frames * nds * Kd * bps // 8)
+    d_bu = poisoned(om, n_frames * nds * Kd * bps)
+    d_tsr = poisoned(om, n_frames * 16)
     assert rx.demod_frames(d_iq, n_frames, frame_len, frame_len, d_eq, d_bp, om.BITS_PACKED, d_tsr) == nds
     rx.demod_frames(d_iq, n_frames, frame_len, frame_len, None, d_bu, om.BITS_UNPACKED, None)
     eq = d_eq.download(np.complex64, n_frames * nds * Kd).reshape(n_frames, nds, Kd)
