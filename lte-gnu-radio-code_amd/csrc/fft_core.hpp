@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 
 #define OFDM_HD __host__ __device__ __forceinline__
+#ifndef OFDM_B_SWZ_RL8
+#define OFDM_B_SWZ_RL8 0
+#endif
 
 namespace ofdm {
 
@@ -61,6 +64,22 @@ OFDM_HD void cmul3(cf& a0, cf b0, cf& a1, cf b1, cf& a2, cf b2) {
     a0 = cmul(a0, b0);
     a1 = cmul(a1, b1);
     a2 = cmul(a2, b2);
+#endif
+}
+
+// the same for two pairs
+OFDM_HD void cmul2(cf& a0, cf b0, cf& a1, cf b1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    cf t0, t1;
+    asm("v_pk_mul_f32 %2, %0, %4 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %1, %5 op_sel:[1,1] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %0, %4, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %5, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1]"
+        : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1)
+        : "v"(b0), "v"(b1));
+#else
+    a0 = cmul(a0, b0);
+    a1 = cmul(a1, b1);
 #endif
 }
 
@@ -138,10 +157,12 @@ struct Plan {
     // workgroups per CU instead of two), unpadded with the column ROTATED by the row: element (c, n) at c*RL + ((n + c + c/16) % RL).
     // Both forms are conflict-free for the ds_write_b64 of pass 1 (16-lane groups) and the ds_read_b64 of the last pass (32-lane
     // groups); tests/test_fft_core_host.py checks the bank rule on the index functions themselves.
-    static constexpr bool B_SWZ = THREE && RL == 16;
+    // The same rotation exists for rows of 8 (2048-pt): column (n + c/2 + c/16) % 8.  OFDM_B_SWZ_RL8 selects it (geometry
+    // study of DESIGN.md 4.1: 4 symbol slots per workgroup, 8 symbols in flight per CU).
+    static constexpr bool B_SWZ = THREE && (RL == 16 || (RL == 8 && OFDM_B_SWZ_RL8 != 0));
     static constexpr int LDS_B = B_SWZ ? NC * RL : NC * (RL + 1);   // exchange B elements
     // pass-1 twiddle table: all 15 powers per n2 (16*RL entries), or only W^1, W^2, W^4, W^8 (4*RL entries, 4096-pt: LDS again)
-    static constexpr bool W1_COMPACT = B_SWZ;
+    static constexpr bool W1_COMPACT = THREE && RL == 16;
     static constexpr int W1_ELEMS = THREE ? (W1_COMPACT ? 4 * RL : 16 * RL) : 0;
     static constexpr int LDS_ELEMS = (LDS_A > LDS_B ? LDS_A : LDS_B) > N ? (LDS_A > LDS_B ? LDS_A : LDS_B) : N;
     static constexpr int SLOTS = (T >= 64) ? 1 : 64 / T;   // symbols handled side by side in one workgroup
@@ -183,8 +204,10 @@ OFDM_HD void load_twiddles(CompactTwiddles<N>& tw, const cf* __restrict__ table,
 template <int N>
 OFDM_HD int b_index(int c, int n) {
     using PL = Plan<N>;
-    if constexpr (PL::B_SWZ)
-        return c * PL::RL + ((n + c + (c >> 4)) & (PL::RL - 1));
+    if constexpr (PL::B_SWZ && PL::RL == 16)
+        return c * 16 + ((n + c + (c >> 4)) & 15);
+    else if constexpr (PL::B_SWZ)                               // RL == 8
+        return c * 8 + ((n + (c >> 1) + (c >> 4)) & 7);
     else
         return c * (PL::RL + 1) + n;
 }
@@ -284,9 +307,20 @@ OFDM_HD void fft_pass1_load(cf (&v)[Plan<N>::P], const cf* lds, int t) {
     for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds[k0 * (PL::T + 2) + n1 * PL::RL + n2];
 }
 
+// The rotated layouts cost one add + and per element address.  Those addresses do not depend on the symbol, so hipcc hoists all
+// 16 of them out of the caller's symbol loop and holds (or spills) 16 VGPRs for the kernel's lifetime; an opaque copy of the
+// lane index keeps the arithmetic where it is used (32 VALU per symbol and pass instead).
+OFDM_HD int opaque_lane(int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+
 template <int N>
 OFDM_HD void fft_pass1_store(cf (&v)[Plan<N>::P], cf* lds, const cf* w1tab, int t) {
     using PL = Plan<N>;
+    if constexpr (PL::B_SWZ) t = opaque_lane(t);
     const int n2 = t >> 4, k0 = t & 15;
     dft_dif<16, 0, 1, PL::P>(v);
     if constexpr (PL::W1_COMPACT) {
@@ -310,6 +344,7 @@ OFDM_HD void fft_pass1_store(cf (&v)[Plan<N>::P], cf* lds, const cf* w1tab, int 
 template <int N>
 OFDM_HD void fft_last_load(cf (&v)[Plan<N>::P], const cf* lds, int t) {
     using PL = Plan<N>;
+    if constexpr (PL::B_SWZ) t = opaque_lane(t);
 #pragma unroll
     for (int j = 0; j < PL::C; ++j) {
         const int c = t + PL::T * j;

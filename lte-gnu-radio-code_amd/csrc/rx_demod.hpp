@@ -21,6 +21,26 @@
 
 #include "ofdm_launch.hpp"
 
+// geometry knobs of the 2048-pt kernel (defaults = the shipped geometry; the alternatives are built by `make geom`)
+#ifndef OFDM_NS_T128
+#define OFDM_NS_T128 2          // symbol slots per workgroup where a symbol is owned by 128 lanes
+#endif
+#ifndef OFDM_MINW_T128
+#define OFDM_MINW_T128 3        // __launch_bounds__ waves per SIMD of that kernel (4 -> a 128-VGPR budget)
+#endif
+#ifndef OFDM_FLAGS_T128
+#define OFDM_FLAGS_T128 0u      // DemodFlags of that kernel
+#endif
+#ifndef OFDM_LANE_TW
+#define OFDM_LANE_TW 1          // 1: all 15 pass-0 twiddles of a lane in VGPRs (30) instead of 4 base values + 11 products per symbol
+#endif
+#ifndef OFDM_SCATTER_HOIST
+#define OFDM_SCATTER_HOIST 1    // 1: the 16 list offsets of a lane may be hoisted out of the symbol loop (16 VGPRs, ~50 VALU less)
+#endif
+#ifndef OFDM_SCATTER_SKIP
+#define OFDM_SCATTER_SKIP 1     // 1: register slots without a listed bin are skipped by a scalar branch
+#endif
+
 namespace ofdm {
 
 // BitRecovery's hard decision for float32 inputs (oracle/ofdm_oracle.py:demap_hard has the derivation):
@@ -268,8 +288,8 @@ __device__ __forceinline__ unsigned pack2(const cf (&z)[2]) {
 
 // one-bit-per-byte output of the PAIR of list entries sym0, sym0 + 1 held by one lane (dense output mapping)
 template <int MOD>
-__device__ __forceinline__ void store_bits_pair_unpacked(uint8_t* bits, int64_t sym0, const cf (&z)[2]) {
-    uint8_t* o = bits + sym0 * MOD;
+__device__ __forceinline__ void store_bits_pair_unpacked(uint8_t* row, unsigned sym0, const cf (&z)[2]) {
+    uint8_t* o = row + sym0 * unsigned(MOD);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const unsigned hb = hard_bits<MOD>(z[e]);
@@ -279,9 +299,10 @@ __device__ __forceinline__ void store_bits_pair_unpacked(uint8_t* bits, int64_t 
 }
 
 // the 4*MOD bits `w` of the list entries sym0 .. sym0 + 3 (sym0 % 4 == 0), MSB first, as MOD/2 bytes
+// `row` = address of the row's first byte (the caller folds everything wave-uniform into it), sym0 = entry index within the row
 template <int MOD>
-__device__ __forceinline__ void store_packed4(uint8_t* bits, int64_t sym0, unsigned w) {
-    uint8_t* o = bits + sym0 * MOD / 8;
+__device__ __forceinline__ void store_packed4(uint8_t* row, unsigned sym0, unsigned w) {
+    uint8_t* o = row + (sym0 >> 2) * unsigned(MOD / 2);
     if constexpr (MOD == 2) {
         o[0] = uint8_t(w);
     } else if constexpr (MOD == 4) {
@@ -297,7 +318,7 @@ __device__ __forceinline__ void store_packed4(uint8_t* bits, int64_t sym0, unsig
 template <int MOD, int BMODE, bool ASMB = true>
 __device__ __forceinline__ void store_bits(uint8_t* bits, int64_t sym0, const cf (&z)[4], int cnt) {
     if constexpr (BMODE == 1) {            // packed MSB-first: 4 symbols -> MOD/2 bytes (host guarantees Kd % 4 == 0, MOD even)
-        store_packed4<MOD>(bits, sym0, pack4<MOD, ASMB>(z));
+        store_packed4<MOD>(bits + (sym0 >> 2) * (MOD / 2), 0u, pack4<MOD, ASMB>(z));
     } else if constexpr (BMODE == 2) {     // one bit per byte
         uint8_t* o = bits + sym0 * MOD;
 #pragma unroll
@@ -318,7 +339,7 @@ __device__ __forceinline__ void store_bits(uint8_t* bits, int64_t sym0, const cf
 template <int N>
 struct DemodGeom {
     static constexpr int T = Plan<N>::T;
-    static constexpr int NS = (T >= 256) ? 1 : (T >= 128) ? 2 : (T >= 64 ? 2 : 64 / T);
+    static constexpr int NS = (T >= 256) ? 1 : (T >= 128) ? OFDM_NS_T128 : (T >= 64 ? 2 : 64 / T);
     static constexpr int WG = T * NS;
     static constexpr int W1_OFF = WgLds<N>::STRIDE * NS;                    // cf units
     static constexpr int G_OFF = W1_OFF + WgLds<N>::W1_ELEMS;
@@ -339,19 +360,23 @@ enum DemodFlags : unsigned {
     DF_L2_INPUT = 1u << 7,       // every workgroup reads frame (blockIdx % 8): cache-resident input, WRONG results, timing only
     DF_LANE_TWIDDLES = 1u << 8,  // all 15 pass-0 twiddles of a lane in VGPRs instead of 4 base values + products
     DF_PSUM_READBACK = 1u << 9,  // power sum by a separate LDS read pass over the staged list (round-1 form)
+    DF_GAINS_VGPR = 1u << 14,    // dense mapping only: a lane keeps the 16 gains of ITS list entries in 32 VGPRs for the whole chunk
+                                 // (no LDS copy of the gains, no gain reads in the symbol loop)
     DF_FOUR_PER_LANE = 1u << 10, // output mapping of round 1 at every size: a lane owns 4 consecutive list entries (two 16 B
                                  // stores 32 B apart: every store instruction of a wave covers 2 KB half-filled)
 };
 
 template <int N, int MOD, int BMODE, int MINW, unsigned FLAGS = 0>
 __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev rx, DemodArgs a) {
-    constexpr bool ROT = (FLAGS & DF_ROT) != 0, HG = (FLAGS & DF_HG) != 0, GLDS = (FLAGS & DF_GAINS_GLOBAL) == 0,
+    constexpr bool ROT = (FLAGS & DF_ROT) != 0, HG = (FLAGS & DF_HG) != 0,
+                   GREG = (FLAGS & DF_GAINS_VGPR) != 0 && Plan<N>::T >= 64 && (FLAGS & DF_FOUR_PER_LANE) == 0 && !(MOD == 1 && BMODE == 1),
+                   GLDS = (FLAGS & DF_GAINS_GLOBAL) == 0 && !GREG,
                    // The IQ stream is read once and the equalised symbols are written once: both carry the non-temporal hint.
                    // It pays only with the dense output mapping (a store instruction covering whole lines): -2.1 % there, while
                    // on the half-filled 2 KB spans of the 4-entries-per-lane mapping it cost +7.6 %.  Below 1024-pt: plain.
                    NTL = (FLAGS & DF_TEMPORAL_LD) == 0 && Plan<N>::T >= 64, NT = (FLAGS & DF_TEMPORAL_ST) == 0 && Plan<N>::T >= 64, ASMB = (FLAGS & DF_GENERIC_BITS) == 0, STAMP = (FLAGS & DF_STAMP) != 0,
                    PIPE = (FLAGS & DF_NO_PIPE) == 0, L2IN = (FLAGS & DF_L2_INPUT) != 0,
-                   CT = (FLAGS & DF_LANE_TWIDDLES) == 0 && Plan<N>::R0 == 16, PSE = (FLAGS & DF_PSUM_READBACK) == 0,
+                   CT = (FLAGS & DF_LANE_TWIDDLES) == 0 && !OFDM_LANE_TW && Plan<N>::R0 == 16, PSE = (FLAGS & DF_PSUM_READBACK) == 0,
                    // dense output mapping (N >= 1024): a lane owns two PAIRS of list entries 128 apart, so that each store
                    // instruction of a wave covers 1 KB contiguously and the LDS list is read at a 16 B lane stride
                    DENSE = Plan<N>::T >= 64 && (FLAGS & DF_FOUR_PER_LANE) == 0 && !(MOD == 1 && BMODE == 1);
@@ -400,7 +425,19 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     if constexpr (GLDS) {
         for (int i = 2 * tid; i < Kd; i += 2 * DG::WG) *reinterpret_cast<float4*>(glds + i) = *reinterpret_cast<const float4*>(gain + i);
     }
+    // GREG: the gains of the two pairs a lane owns per q (dense mapping: idx = 4 T q + 256 wave + 128 half + 2 lane)
+    float4 greg[GREG ? Q : 1][2];
+    if constexpr (GREG) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx) {
+                const int idx = 4 * T * q + 256 * (t >> 6) + 128 * hx + 2 * (t & 63);
+                greg[q][hx] = idx < Kd ? *reinterpret_cast<const float4*>(gain + idx) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
 
+    const float sqrt_kd = sqrtf(float(Kd));
     const int n_iter = (a.spc + NS - 1) / NS;
     // STAMP (diagnostic build only, never timed): cycles per phase, summed over the chunk, one row per wave
     unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -447,12 +484,17 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         } else {                                                         // short tail: fft(x, N) zero-pads (:230)
             const int64_t last = a.frame_len > 0 ? a.frame_len - 1 : 0;
             const bool any = sy.compute && a.frame_len > 0;
+            // Rare path.  Its 16 clamped element addresses are loop-invariant up to the symbol offset, and hipcc hoists what it can
+            // out of the symbol loop: 26 VGPRs held (or spilled) for the whole kernel.  The lane index therefore passes through an
+            // opaque copy HERE, so everything below is computed where it is used.
+            int tq = t;
+            asm volatile("" : "+v"(tq));
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) {
-                const int64_t idx = sy.start + t + T * n0;
+                const int64_t idx = sy.start + tq + T * n0;
                 const cf x = any ? frame_iq[idx < 0 ? 0 : (idx < last ? idx : last)] : cf{0.f, 0.f};
                 v[n0] = (any && idx >= 0 && idx < a.frame_len) ? x : cf{0.f, 0.f};
-                if constexpr (ROT) v[n0] = cmul(v[n0], a.rot[t + T * n0]);
+                if constexpr (ROT) v[n0] = cmul(v[n0], a.rot[tq + T * n0]);
             }
         }
     };
@@ -493,7 +535,9 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
 
         // Re-materialise Kd per symbol so hipcc does not hoist 16 per-slot list offsets into VGPRs held across the loop.
         int Kd_ = Kd;
+#if !OFDM_SCATTER_HOIST
         asm volatile("" : "+s"(Kd_));
+#endif
         const int hk = Kd_ >> 1;
         // :232 gather into bin-list order: negative half i = k-(N-Kd/2), positive half i = Kd/2+k-1.
         // Unlisted bins fall past the list (i in [Kd, N-2]) and DC is parked at index N (< LDS_ELEMS): no branches.
@@ -503,6 +547,14 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
             for (int kl = 0; kl < PL::RL; ++kl) {
+#if OFDM_SCATTER_SKIP
+                // a register slot holds the T consecutive bins [base, base + T): where none of them is listed (wave-uniform, scalar
+                // test) there is nothing to stage and nothing to add to the power sum
+                if constexpr (T >= 64) {
+                    const int base = T * j + PL::NC * kl;                  // a constant once the loops are unrolled
+                    if (base > hk && base + T - 1 < N - hk) continue;
+                }
+#endif
                 const int k = (t + T * j) + PL::NC * kl;
                 int i = k + ((k >= N - hk) ? off_neg : off_pos);
                 if (j == 0 && kl == 0) i = (k == 0) ? N : i;             // only this slot can hold DC
@@ -568,7 +620,9 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 for (int w = 0; w < T / 64; ++w) psum += red[w];
             }
         }
-        const float scale = sqrtf(float(Kd_) / psum);                    // :233 p_est0
+        // :233 p_est0 = sqrt(Kd / P) = sqrt(Kd) * rsq(P): v_rsq_f32 is good to 1 ulp, far inside the 1e-5 bar; the IEEE division and
+        // square root this replaces were ~30 VALU per wave and symbol.  P = 0 (an empty window) gives inf, as before.
+        const float scale = sqrt_kd * __builtin_amdgcn_rsqf(psum);
         stamp(5);                                                        // .. list read + power sum
 
         // A pattern whose guard failed (:223) keeps the zero rows est_data_freq was created with (:88): in batch mode they are
@@ -577,9 +631,11 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         if (!compute) {
             if (sym_valid && a.zero_skipped) {
                 const cf zz[4] = {cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}, cf{0.f, 0.f}};
+                int tq = t;                                              // rare path: nothing of it may be hoisted into VGPRs (see load_sym)
+                asm volatile("" : "+v"(tq));
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const int idx = 4 * (t + T * q);
+                    const int idx = 4 * (tq + T * q);
                     if (idx < Kd_) {
                         const bool four = idx + 2 < Kd_;
                         if (a.eq) {
@@ -592,45 +648,67 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 }
             }
         } else if constexpr (DENSE) {
-            {
-                const int wv = t >> 6, ln = t & 63;
+            // Dense mapping: per q a WAVE owns two blocks of 128 consecutive list entries (bases 4Tq + 256 wave + {0, 128}), a lane
+            // one pair of each.  Whether a block lies inside the list is the same for the whole wave, so it is decided on the
+            // scalar unit: blocks past the list are skipped by a branch, blocks wholly inside run without touching exec, and only
+            // the one block that straddles Kd is lane-masked.  Row bases are scalar too: every store is `scalar base + 32-bit lane
+            // offset` (the 64-bit address chains this replaces were ~60 VALU per wave and symbol).
+            const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;      // scalar: block decisions
+            const int lane_e = ((t >> 6) << 8) + 2 * ln;                                 // vector, loop-invariant: this lane's entry in block 0
+            const int64_t row0 = orow * Kd_;                                             // uniform per slot
+            cf* const eq_row = a.eq ? a.eq + row0 : nullptr;
+            uint8_t* const bits_row = (BMODE == 0) ? nullptr : (BMODE == 1) ? a.bits + ((row0 * MOD) >> 3) : a.bits + row0 * MOD;
+            const cf* const l_lane = lds + lane_e;
+            const cf* const g_lane = gsrc + lane_e;
+            const unsigned eq_off = unsigned(lane_e) * unsigned(sizeof(cf));             // byte offset of the lane's pair within a row
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    unsigned wp[2] = {0u, 0u};                         // packed bits of this lane's two pairs
-                    int idxp[2];
+            for (int q = 0; q < Q; ++q) {
+                const int b0 = 4 * T * q + 256 * wv;                                      // scalar
+                if (b0 < Kd_) {
+                    unsigned wp[2] = {0u, 0u};                                            // packed bits of this lane's two pairs
 #pragma unroll
                     for (int hx = 0; hx < 2; ++hx) {
-                        const int idx = 4 * T * q + 256 * wv + 128 * hx + 2 * ln;        // Kd is even: a pair is in or out as one
-                        idxp[hx] = idx;
-                        if (idx < Kd_) {
-                            const float4 g = *reinterpret_cast<const float4*>(gsrc + idx);
-                            const float4 av = *reinterpret_cast<const float4*>(lds + idx);
+                        const int base = b0 + 128 * hx;
+                        const int cofs = 4 * T * q + 128 * hx;                            // compile-time part of the block base
+                        auto pair = [&]() {
+                            float4 g;
+                            if constexpr (GREG)
+                                g = greg[q][hx];
+                            else
+                                g = *reinterpret_cast<const float4*>(g_lane + cofs);
+                            const float4 av = *reinterpret_cast<const float4*>(l_lane + cofs);
                             // :235-248  x * p_est0 * e^{j..} * gain
-                            const cf z[2] = {cmul(cf{av.x, av.y} * scale, cf{g.x, g.y}), cmul(cf{av.z, av.w} * scale, cf{g.z, g.w})};
-                            if (a.eq) {
-                                const float4 o4 = float4{z[0].x, z[0].y, z[1].x, z[1].y};
+                            cf z[2] = {cf{av.x, av.y} * scale, cf{av.z, av.w} * scale};
+                            cmul2(z[0], cf{g.x, g.y}, z[1], cf{g.z, g.w});
+                            if (eq_row) {
                                 typedef float f4 __attribute__((ext_vector_type(4)));
-                                [[maybe_unused]] const f4 ov = f4{o4.x, o4.y, o4.z, o4.w};
-                                [[maybe_unused]] cf* op = a.eq + orow * Kd_ + idx;
+                                const f4 ov = f4{z[0].x, z[0].y, z[1].x, z[1].y};
+                                // scalar block address + the lane's constant 32-bit byte offset: no address arithmetic on the VALU
+                                cf* const blk = eq_row + cofs;
 #ifdef OFDM_EXPERIMENTS
                                 // cache-policy study of the output store (FLAGS bits 12-13): sc1 / sc0 sc1 / sc0 sc1 nt
                                 constexpr unsigned SPOL = (FLAGS >> 12) & 3u;
                                 if constexpr (SPOL == 1) {
-                                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(op), "v"(ov) : "memory");
+                                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(eq_off), "v"(ov), "s"(blk) : "memory");
                                 } else if constexpr (SPOL == 2) {
-                                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(op), "v"(ov) : "memory");
+                                    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(eq_off), "v"(ov), "s"(blk) : "memory");
                                 } else if constexpr (SPOL == 3) {
-                                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(op), "v"(ov) : "memory");
+                                    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt" ::"v"(eq_off), "v"(ov), "s"(blk) : "memory");
                                 } else
 #endif
                                 if constexpr (NT) {
-                                    __builtin_nontemporal_store(ov, reinterpret_cast<f4*>(op));
+                                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(eq_off), "v"(ov), "s"(blk) : "memory");
                                 } else {
-                                    *reinterpret_cast<float4*>(op) = o4;
+                                    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(eq_off), "v"(ov), "s"(blk) : "memory");
                                 }
                             }
                             if constexpr (BMODE == 1) wp[hx] = pack2<MOD, ASMB>(z);
-                            if constexpr (BMODE == 2) store_bits_pair_unpacked<MOD>(a.bits, orow * Kd_ + idx, z);
+                            if constexpr (BMODE == 2) store_bits_pair_unpacked<MOD>(bits_row + cofs * MOD, unsigned(lane_e), z);
+                        };
+                        if (base + 128 <= Kd_) {                                          // scalar: the whole block is listed
+                            pair();
+                        } else if (base < Kd_) {                                          // scalar: the block that straddles Kd
+                            if (base + 2 * ln < Kd_) pair();
                         }
                     }
                     if constexpr (BMODE == 1) {
@@ -641,8 +719,13 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                         const bool odd = (ln & 1) != 0;
                         const unsigned recv = unsigned(__builtin_amdgcn_mov_dpp(int(odd ? wp[0] : wp[1]), 0xB1, 0xF, 0xF, false));   // quad_perm:[1,0,3,2]
                         const unsigned w4 = odd ? ((recv << (2 * MOD)) | wp[1]) : ((wp[0] << (2 * MOD)) | recv);
-                        const int gidx = odd ? idxp[1] - 2 : idxp[0];
-                        if (gidx < Kd_) store_packed4<MOD>(a.bits, orow * Kd_ + gidx, w4);
+                        const int ge = lane_e + (odd ? 126 : 0);                          // group's first entry relative to 4 T q (vector, loop-invariant)
+                        uint8_t* const brow = bits_row + (4 * T * q / 4) * (MOD / 2);     // scalar
+                        if (b0 + 256 <= Kd_) {
+                            store_packed4<MOD>(brow, unsigned(ge), w4);
+                        } else if (4 * T * q + ge < Kd_) {
+                            store_packed4<MOD>(brow, unsigned(ge), w4);
+                        }
                     }
                 }
             }
@@ -706,7 +789,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         a.chunks_per_frame = int((a.n_dsym + spc - 1) / spc);
     }
     const unsigned grid = unsigned(int64_t(a.n_frames) * a.chunks_per_frame);
-    size_t lds = DG::lds_bytes(rx.Kd, true);
+    size_t lds = DG::lds_bytes(rx.Kd, !(Plan<N>::T == 128 && (OFDM_FLAGS_T128 & (DF_GAINS_GLOBAL | DF_GAINS_VGPR))));
 #ifdef OFDM_EXPERIMENTS
     if (a.variant >= 100) lds += size_t(a.variant - 100) * 1024;   // occupancy experiment: pad the LDS request by (variant-100) KiB
 #endif
@@ -763,8 +846,18 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         }
     }
 #endif
-#define OFDM_LD(M, B) \
-    hipLaunchKernelGGL((rx_demod_kernel<N, M, B, 3>), dim3(grid), dim3(DG::WG), lds, s, rx, a)
+    constexpr int MW = (Plan<N>::T == 128) ? OFDM_MINW_T128 : 3;
+    constexpr unsigned FL = (Plan<N>::T == 128) ? OFDM_FLAGS_T128 : 0u;
+    // more than 64 KB of dynamic LDS per workgroup (4 slots at 2048-pt) has to be announced once per kernel
+#define OFDM_LD(M, B)                                                                                                        \
+    do {                                                                                                                     \
+        if (lds > 65536) {                                                                                                   \
+            static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_demod_kernel<N, M, B, MW, FL>),   \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));             \
+            if (once != hipSuccess) return once;                                                                             \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((rx_demod_kernel<N, M, B, MW, FL>), dim3(grid), dim3(DG::WG), lds, s, rx, a);                     \
+    } while (0)
 #define OFDM_LD_MOD(B)                  \
     switch (a.mod) {                    \
         case 1: OFDM_LD(1, B); break;   \
