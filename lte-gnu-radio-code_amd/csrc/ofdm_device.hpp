@@ -36,12 +36,34 @@ __device__ __forceinline__ bool bin_pos(int k, int K, int& i) {
 }
 
 // ------------------------------------------------------------------------------ reductions over the T lanes of a symbol
+// v of lane (i with the DPP control applied); lanes of rows that ROW_MASK disables, and lanes without a source, read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over the 64 lanes of a wave, returned to every lane: six v_add_f32 with DPP operands (pairs, quads, half rows, rows, then
+// the gfx9 row broadcasts carry row totals forward so that row 3 holds the wave total) and one v_readlane.  The __shfl_xor
+// butterfly this replaces is six ds_bpermute_b32 plus their index arithmetic (~30 VALU and 6 LDS operations per reduction).
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_or_zero<0xB1, 0xF>(v);      // quad_perm:[1,0,3,2]
+    v += dpp_or_zero<0x4E, 0xF>(v);      // quad_perm:[2,3,0,1]
+    v += dpp_or_zero<0x141, 0xF>(v);     // row_half_mirror
+    v += dpp_or_zero<0x140, 0xF>(v);     // row_mirror: every lane of a row holds the row's sum
+    v += dpp_or_zero<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3: row 3 = wave total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <int T>
 __device__ __forceinline__ float lanes_sum(float v) {
-    constexpr int W = T < 64 ? T : 64;
+    if constexpr (T >= 64) {
+        return wave_sum(v);
+    } else {
 #pragma unroll
-    for (int m = W >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+        for (int m = T >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
 }
 
 // Workgroup barrier that orders LDS traffic ONLY.  Every barrier in these kernels protects an LDS exchange

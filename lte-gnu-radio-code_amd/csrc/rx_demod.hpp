@@ -556,6 +556,18 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
                 }
 #endif
                 const int k = (t + T * j) + PL::NC * kl;
+#if OFDM_SCATTER_SKIP
+                if constexpr (T >= 64) {
+                    // ... and where ALL of them are listed (scalar test again) the power term needs no membership mask
+                    const int base = T * j + PL::NC * kl;
+                    const bool all_pos = base >= 1 && base + T - 1 <= hk, all_neg = base >= N - hk && hk < N / 2;
+                    if (all_pos || all_neg) {
+                        lds[k + (all_neg ? off_neg : off_pos)] = v[out_slot<N>(j, kl)];
+                        if constexpr (PSE) pse += cnorm2(v[out_slot<N>(j, kl)]);
+                        continue;
+                    }
+                }
+#endif
                 int i = k + ((k >= N - hk) ? off_neg : off_pos);
                 if (j == 0 && kl == 0) i = (k == 0) ? N : i;             // only this slot can hold DC
                 lds[i] = v[out_slot<N>(j, kl)];
