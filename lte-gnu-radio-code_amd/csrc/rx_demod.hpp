@@ -17,6 +17,8 @@
 // BMODE 0 = no bits, 1 = packed MSB-first, 2 = one bit per byte      } decision code has no runtime switches
 // MINW  __launch_bounds__ min waves per SIMD (register budget; 3 -> 168 VGPRs)
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "ofdm_launch.hpp"
@@ -405,8 +407,11 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     const int64_t chunk = blockIdx.x;
     const int frame = int(chunk / a.chunks_per_frame);
     const int cidx = int(chunk % a.chunks_per_frame);
-    const int ds0 = cidx * a.spc;
-    const int ds1 = min(ds0 + a.spc, a.n_dsym);
+    // Balanced partition of the frame's data symbols into chunks_per_frame runs of whole trips (NS symbols): lengths differ by at
+    // most one trip.  (launch_rx_demod_n explains why equal chunks matter: workgroups go to the 8 XCDs round-robin.)
+    const int trips = (a.n_dsym + NS - 1) / NS;
+    const int ds0 = int(int64_t(cidx) * trips / a.chunks_per_frame) * NS;
+    const int ds1 = min(int(int64_t(cidx + 1) * trips / a.chunks_per_frame) * NS, a.n_dsym);
     constexpr bool active = true;
 
     std::conditional_t<CT, CompactTwiddles<N>, LaneTwiddles<N>> tw;
@@ -438,7 +443,7 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     }
 
     const float sqrt_kd = sqrtf(float(Kd));
-    const int n_iter = (a.spc + NS - 1) / NS;
+    const int n_iter = (ds1 - ds0 + NS - 1) / NS;                         // trips of THIS chunk
     // STAMP (diagnostic build only, never timed): cycles per phase, summed over the chunk, one row per wave
     unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
@@ -459,7 +464,8 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     };
     auto sym_of = [&](int it) {
         Sym sy;
-        const int ds = ds0 + it * NS + slot;
+        const int itr = it;
+        const int ds = ds0 + itr * NS + slot;
         sy.valid = active && it < n_iter && ds < ds1;
         const int p = ds / D, n_ = ds - p * D;
         const int64_t pat_ptr = int64_t(tsr0) + int64_t(S) * L * (int64_t(p) * (S + D) + 1);
@@ -791,14 +797,35 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     using DG = DemodGeom<N>;
     DemodArgs a = a_in;
     if (a.n_frames <= 0 || a.n_dsym <= 0) return hipSuccess;
-    if (a.spc <= 0) {    // auto chunking: ~16k workgroups, every chunk a multiple of NS symbols of one frame
-        const int64_t total = int64_t(a.n_frames) * a.n_dsym;
-        int64_t spc = (total / 16384 + DG::NS - 1) / DG::NS * DG::NS;
-        if (spc < DG::NS) spc = DG::NS;
-        const int64_t cap = (int64_t(a.n_dsym) + DG::NS - 1) / DG::NS * DG::NS;
-        if (spc > cap) spc = cap;
-        a.spc = int(spc);
-        a.chunks_per_frame = int((a.n_dsym + spc - 1) / spc);
+    if (a.chunks_per_frame <= 0) {
+        // Auto chunking.  Workgroup w works on chunk w % cpf of frame w / cpf, and the hardware hands workgroups to the 8 XCDs
+        // round-robin (w % 8) -- statically: an XCD that gets less work is idle at the end, nothing is re-balanced.  With the
+        // round-2 rule (chunks of 48, the remainder in the frame's last chunk: 48 48 48 36 at 180 symbols per frame, cpf = 4)
+        // the short chunk of every frame landed on XCDs 3 and 7, the others carried 6.7 % more than the average, and the
+        // kernel took 5.5 % longer than with equal chunks (profiles/r03_demod_chunking.txt).  So: (1) chunks of EQUAL length
+        // where the frame's trips divide evenly, (2) else lengths that differ by one trip with an ODD chunk count per frame,
+        // so that every XCD sees every chunk index equally often; 20-32 symbols per chunk (the frame's gains are copied
+        // into LDS once per chunk; >= 20 rounds of resident workgroups at the bench sizes keep the tail short).
+        const int trips = (a.n_dsym + DG::NS - 1) / DG::NS;
+        const int64_t total_trips = int64_t(a.n_frames) * trips;
+        constexpr int per_chunk = N >= 2048 ? 32 : 20;                      // symbols per chunk aimed at (A/B: 30 at 2048-pt, 18 at 1024-pt)
+        int want = int(std::max<int64_t>(1, (int64_t(trips) * DG::NS + per_chunk - 1) / per_chunk));
+        if (total_trips / std::max(want, 1) < 4096) want = int(std::max<int64_t>(1, std::min<int64_t>(trips, 4096 / std::max(a.n_frames, 1))));  // few frames: finer
+#ifdef OFDM_TUNE_ENV     // study builds only (make geom GEOMFLAGS=-DOFDM_TUNE_ENV): chunk count per frame from the environment
+        if (const char* e = getenv("OFDM_DEMOD_CPF")) want = atoi(e);
+#endif
+        want = std::max(1, std::min(want, trips));
+        int best = want;
+        if (trips % want != 0) {                                            // nearest divisor of trips within [want/1.5, want*1.5], else odd
+            best = 0;
+            for (int d = 0; d <= want / 2 && !best; ++d) {
+                if (want + d <= trips && trips % (want + d) == 0) best = want + d;
+                else if (want - d >= 1 && trips % (want - d) == 0 && 3 * (want - d) >= 2 * want) best = want - d;
+            }
+            if (!best) best = (want & 1) ? want : std::min(want + 1, trips);
+        }
+        a.chunks_per_frame = best;
+        a.spc = ((trips + best - 1) / best) * DG::NS;                       // longest chunk (informational)
     }
     const unsigned grid = unsigned(int64_t(a.n_frames) * a.chunks_per_frame);
     size_t lds = DG::lds_bytes(rx.Kd, !(Plan<N>::T == 128 && (OFDM_FLAGS_T128 & (DF_GAINS_GLOBAL | DF_GAINS_VGPR))));

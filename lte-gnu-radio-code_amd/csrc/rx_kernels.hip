@@ -500,8 +500,17 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     for (;;) {
         bool blk_on = !found && P0 < nvalid;
         if constexpr (SEG) {
-            // a hit published by an earlier segment ends this one: nothing at or after P0 can be the first accepted trial
-            if (pass == 0 && __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P0) blk_on = false;
+            // A hit published by an earlier segment ends this one: nothing at or after P0 can be the first accepted trial.  Every
+            // thread reads the word itself.  Where one segment spans the whole workgroup (SLOTS == 1) its waves may see different
+            // values, so they vote: ANY wave that saw the earlier hit stops the segment (the word only ever decreases) and blk_on
+            // is workgroup-uniform as the anchor trial below assumes.  Where a workgroup holds several segments (SLOTS > 1) a
+            // segment lies inside one wave, whose lanes read the word in one instruction: uniform per segment without a vote.
+            const bool stop = pass == 0 && __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P0;
+            if constexpr (SLOTS == 1) {
+                if (__syncthreads_or(stop ? 1 : 0)) blk_on = false;
+            } else if (stop) {
+                blk_on = false;
+            }
         }
         if (!__syncthreads_or(blk_on ? 1 : 0)) break;
         SCAN_STAMP(0);
@@ -843,35 +852,6 @@ __device__ __forceinline__ void demap_hard_words(const cf (&z)[4], uint32_t (&w)
         }
     }
 }
-template <int MOD>
-__global__ void __launch_bounds__(256) demap_hard_kernel(DemapArgs a) {
-    const int64_t n = a.n, n4 = n >> 2;
-    const bool wide = ((reinterpret_cast<uintptr_t>(a.sym) | reinterpret_cast<uintptr_t>(a.hard)) & 15) == 0;
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
-    if (wide) {
-        for (int64_t g = gid; g < n4; g += stride) {
-            const float4 v0 = reinterpret_cast<const float4*>(a.sym)[2 * g], v1 = reinterpret_cast<const float4*>(a.sym)[2 * g + 1];
-            const cf z[4] = {cf{v0.x, v0.y}, cf{v0.z, v0.w}, cf{v1.x, v1.y}, cf{v1.z, v1.w}};
-            uint32_t w[MOD];
-            demap_hard_words<MOD>(z, w);
-            uint32_t* o = reinterpret_cast<uint32_t*>(a.hard + g * 4 * MOD);
-            if constexpr (MOD == 4) {
-                *reinterpret_cast<uint4*>(o) = uint4{w[0], w[1], w[2], w[3]};
-            } else if constexpr (MOD == 1) {
-                o[0] = w[0];
-            } else {                                                   // 8 or 24 bytes, 8-byte aligned
-#pragma unroll
-                for (int k = 0; k < MOD; k += 2) *reinterpret_cast<uint2*>(o + k) = uint2{w[k], w[k + 1]};
-            }
-        }
-    }
-    for (int64_t i = (wide ? n4 * 4 : 0) + gid; i < n; i += stride) {
-        const unsigned hb = hard_bits<MOD>(a.sym[i]);
-#pragma unroll
-        for (int b = 0; b < MOD; ++b) a.hard[i * MOD + b] = uint8_t((hb >> (MOD - 1 - b)) & 1u);
-    }
-}
-
 __device__ __forceinline__ void qpsk_nearest(cf z, bool& re_pos, bool& im_pos, cf& e) {
     // quadrant tests in the reference's order ++, -+, --, +- (BitRecovery.py:106-125)
     re_pos = (z.x > 0.f) || (z.x == 0.f && z.y >= 0.f);
@@ -880,24 +860,12 @@ __device__ __forceinline__ void qpsk_nearest(cf z, bool& re_pos, bool& im_pos, c
     e = cf{z.x - (re_pos ? c : -c), z.y - (im_pos ? c : -c)};                            // :93-98
 }
 
-// pass 1: partial sums of dmin (double) -> a.partial[blockIdx]   (BitRecovery.py:88,102)
-__global__ void __launch_bounds__(256) demap_dmin_kernel(DemapArgs a) {
-    __shared__ double sh[256];
-    double acc = 0.0;
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
-        bool rp, ip;
-        cf e;
-        qpsk_nearest(a.sym[i], rp, ip, e);
-        acc += double(sqrtf(cnorm2(e)));
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    // more workgroups than partial slots (256 of them cannot keep the memory system busy): the slots are zeroed by the launcher
-    if (threadIdx.x == 0) atomicAdd(a.partial + (blockIdx.x % DEMAP_PARTIALS), sh[0]);
+__device__ __forceinline__ void store_stream16(float* p, float4 v);
+// 16-byte load of data this kernel reads once
+__device__ __forceinline__ float4 load_stream16(const float* p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    return float4{v.x, v.y, v.z, v.w};
 }
 
 // pass 2: llrp0 / llrp1 (BitRecovery.py:102-125)
@@ -932,8 +900,8 @@ __global__ void __launch_bounds__(256) demap_soft_kernel(DemapArgs a) {
         float a0[2], a1[2], b0[2], b1[2];
         metrics(cf{v.x, v.y}, a0, a1);
         metrics(cf{v.z, v.w}, b0, b1);
-        if (a.soft0) reinterpret_cast<float4*>(a.soft0)[g] = float4{a0[0], a0[1], b0[0], b0[1]};
-        if (a.soft1) reinterpret_cast<float4*>(a.soft1)[g] = float4{a1[0], a1[1], b1[0], b1[1]};
+        if (a.soft0) store_stream16(a.soft0 + 4 * g, float4{a0[0], a0[1], b0[0], b0[1]});
+        if (a.soft1) store_stream16(a.soft1 + 4 * g, float4{a1[0], a1[1], b1[0], b1[1]});
     }
     for (int64_t i = n2 * 2 + gid; i < a.n; i += stride) {
         float m0[2], m1[2];
@@ -986,25 +954,82 @@ struct Pam {
     }
 };
 
-template <int BPS>
-__global__ void __launch_bounds__(256) demap_dmin_qam_kernel(DemapArgs a) {
-    __shared__ double sh[256];
+// distance of one symbol to its nearest constellation point (BitRecovery.py:87-88; the QAM extension's own definition)
+template <int MOD>
+__device__ __forceinline__ float demap_dmin(cf z) {
+    if constexpr (MOD == 2) {
+        bool rp, ip;
+        cf e;
+        qpsk_nearest(z, rp, ip, e);
+        return sqrtf(cnorm2(e));
+    } else {
+        float d0[Pam<MOD>::NB], d1[Pam<MOD>::NB], ex, ey;
+        Pam<MOD>::dist(z.x, d0, d1, ex);
+        Pam<MOD>::dist(z.y, d0, d1, ey);
+        return sqrtf(ex * ex + ey * ey);
+    }
+}
+
+// Pass 1 of the de-mapper, ONE read of the symbols: hard bits (one per byte; a thread takes FOUR consecutive symbols -- two 16 B
+// loads -- and writes their 4*MOD bytes as whole words) and / or the partial sums of the nearest-point distances that sigma
+// needs (BitRecovery.py:88,102: double partial sums, added atomically into DEMAP_PARTIALS slots zeroed by the launcher).
+// Round 2 ran these as two kernels: hard + soft output read every symbol three times.
+template <int MOD, bool HARD, bool DMIN>
+__global__ void __launch_bounds__(256) demap_pass1_kernel(DemapArgs a) {
+    const int64_t n = a.n, n4 = n >> 2;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a.sym) | (HARD ? reinterpret_cast<uintptr_t>(a.hard) : 0)) & 15) == 0;
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
     double acc = 0.0;
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+    if (wide) {
+        for (int64_t g = gid; g < n4; g += stride) {
+            const float4 v0 = load_stream16(reinterpret_cast<const float*>(a.sym) + 8 * g),
+                         v1 = load_stream16(reinterpret_cast<const float*>(a.sym) + 8 * g + 4);
+            const cf z[4] = {cf{v0.x, v0.y}, cf{v0.z, v0.w}, cf{v1.x, v1.y}, cf{v1.z, v1.w}};
+            if constexpr (DMIN) {
+                // four float distances summed in float (exact enough: 4 terms), the running sum in double
+                acc += double((demap_dmin<MOD>(z[0]) + demap_dmin<MOD>(z[1])) + (demap_dmin<MOD>(z[2]) + demap_dmin<MOD>(z[3])));
+            }
+            if constexpr (HARD) {
+                uint32_t w[MOD];
+                demap_hard_words<MOD>(z, w);
+                uint32_t* o = reinterpret_cast<uint32_t*>(a.hard + g * 4 * MOD);
+                if constexpr (MOD == 4) {
+                    *reinterpret_cast<uint4*>(o) = uint4{w[0], w[1], w[2], w[3]};
+                } else if constexpr (MOD == 1) {
+                    o[0] = w[0];
+                } else {                                                   // 8 or 24 bytes, 8-byte aligned
+#pragma unroll
+                    for (int k = 0; k < MOD; k += 2) *reinterpret_cast<uint2*>(o + k) = uint2{w[k], w[k + 1]};
+                }
+            }
+        }
+    }
+    for (int64_t i = (wide ? n4 * 4 : 0) + gid; i < n; i += stride) {
         const cf z = a.sym[i];
-        float d0[Pam<BPS>::NB], d1[Pam<BPS>::NB], ex, ey;
-        Pam<BPS>::dist(z.x, d0, d1, ex);
-        Pam<BPS>::dist(z.y, d0, d1, ey);
-        acc += double(sqrtf(ex * ex + ey * ey));
+        if constexpr (DMIN) acc += double(demap_dmin<MOD>(z));
+        if constexpr (HARD) {
+            const unsigned hb = hard_bits<MOD>(z);
+#pragma unroll
+            for (int b = 0; b < MOD; ++b) a.hard[i * MOD + b] = uint8_t((hb >> (MOD - 1 - b)) & 1u);
+        }
     }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    if constexpr (DMIN) {
+        __shared__ double sh[256];
+        sh[threadIdx.x] = acc;
         __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        // more workgroups than partial slots (256 of them cannot keep the memory system busy)
+        if (threadIdx.x == 0) atomicAdd(a.partial + (blockIdx.x % DEMAP_PARTIALS), sh[0]);
     }
-    // more workgroups than partial slots (256 of them cannot keep the memory system busy): the slots are zeroed by the launcher
-    if (threadIdx.x == 0) atomicAdd(a.partial + (blockIdx.x % DEMAP_PARTIALS), sh[0]);
+}
+
+// 16-byte store of data that is written once and not read again by this kernel
+__device__ __forceinline__ void store_stream16(float* p, float4 v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
 }
 
 template <int BPS>
@@ -1035,14 +1060,82 @@ __global__ void __launch_bounds__(256) demap_soft_qam_kernel(DemapArgs a) {
         }
         // BPS floats per symbol = 16 B (16-QAM: one 16 B store where the buffer allows it) / 24 B (64-QAM: three 8 B stores)
         if (BPS == 4 && wide) {
-            if (a.soft0) *reinterpret_cast<float4*>(a.soft0 + i * BPS) = float4{o0[0], o0[1], o0[2], o0[3]};
-            if (a.soft1) *reinterpret_cast<float4*>(a.soft1 + i * BPS) = float4{o1[0], o1[1], o1[2], o1[3]};
+            if (a.soft0) store_stream16(a.soft0 + i * BPS, float4{o0[0], o0[1], o0[2], o0[3]});
+            if (a.soft1) store_stream16(a.soft1 + i * BPS, float4{o1[0], o1[1], o1[2], o1[3]});
         } else {
 #pragma unroll
             for (int b = 0; b < BPS; b += 2) {
                 if (a.soft0) *reinterpret_cast<float2*>(a.soft0 + i * BPS + b) = make_float2(o0[b], o0[b + 1]);
                 if (a.soft1) *reinterpret_cast<float2*>(a.soft1 + i * BPS + b) = make_float2(o1[b], o1[b + 1]);
             }
+        }
+    }
+}
+
+// 64-QAM soft metrics with DENSE stores.  A symbol owns 6 floats per metric array, so a lane that keeps "its" symbols writes 24 B
+// pieces at a 24 B stride: every store instruction of a wave touches 12+ lines partially (0.39 of the HBM rate with both arrays,
+// round 2).  Here a wave takes a tile of 128 symbols (one 16 B load per lane = 2 symbols), parks each array's 768 floats in LDS
+// in symbol order and writes them back as 192 pieces of 16 B, piece k*64 + lane per store instruction: 1 KB contiguous, written
+// once, non-temporal.  The staging area is private to the wave (LDS is in order per wave: a counter wait, no barrier).
+__global__ void __launch_bounds__(256) demap_soft_qam64_kernel(DemapArgs a) {
+    constexpr int BPS = 6, NB = 3, TILE = 128;
+    __shared__ __attribute__((aligned(16))) float stage[4][2][TILE * BPS];               // 4 waves x 2 arrays x 3 KB
+    __shared__ double sh_tot;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < DEMAP_PARTIALS; ++i) s += a.partial[i];
+        sh_tot = s;
+    }
+    __syncthreads();
+    const double sigma = 0.7071067811865476 * (sh_tot / double(a.n));
+    const float hf = float(-0.5 / (sigma * sigma));
+    auto metrics = [&](cf z, float (&o0)[BPS], float (&o1)[BPS]) {
+        float r0[NB], r1[NB], i0[NB], i1[NB], e;
+        Pam<BPS>::dist(z.x, r0, r1, e);
+        Pam<BPS>::dist(z.y, i0, i1, e);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            o0[2 * j] = hf * r0[j];
+            o0[2 * j + 1] = hf * i0[j];
+            o1[2 * j] = hf * r1[j];
+            o1[2 * j + 1] = hf * i1[j];
+        }
+    };
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a.sym) | reinterpret_cast<uintptr_t>(a.soft0) | reinterpret_cast<uintptr_t>(a.soft1)) & 15) == 0;
+    const int64_t n_tiles = wide ? a.n / TILE : 0;
+    float* st0 = stage[wave][0];
+    float* st1 = stage[wave][1];
+    for (int64_t tile = int64_t(blockIdx.x) * 4 + wave; tile < n_tiles; tile += int64_t(gridDim.x) * 4) {
+        const float4 v = load_stream16(reinterpret_cast<const float*>(a.sym) + 4 * (tile * (TILE / 2) + lane));
+        float p0[BPS], p1[BPS], q0[BPS], q1[BPS];
+        metrics(cf{v.x, v.y}, p0, p1);                                                    // symbol 2*lane of the tile
+        metrics(cf{v.z, v.w}, q0, q1);                                                    // symbol 2*lane + 1
+        float4* w0 = reinterpret_cast<float4*>(st0 + lane * 2 * BPS);
+        float4* w1 = reinterpret_cast<float4*>(st1 + lane * 2 * BPS);
+        w0[0] = float4{p0[0], p0[1], p0[2], p0[3]};
+        w0[1] = float4{p0[4], p0[5], q0[0], q0[1]};
+        w0[2] = float4{q0[2], q0[3], q0[4], q0[5]};
+        w1[0] = float4{p1[0], p1[1], p1[2], p1[3]};
+        w1[1] = float4{p1[4], p1[5], q1[0], q1[1]};
+        w1[2] = float4{q1[2], q1[3], q1[4], q1[5]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              // wave-local exchange: in order per wave
+        const int64_t obase = tile * (TILE * BPS);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int piece = k * 64 + lane;
+            if (a.soft0) store_stream16(a.soft0 + obase + 4 * piece, *reinterpret_cast<const float4*>(st0 + 4 * piece));
+            if (a.soft1) store_stream16(a.soft1 + obase + 4 * piece, *reinterpret_cast<const float4*>(st1 + 4 * piece));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              // reads done before the next tile overwrites
+    }
+    for (int64_t i = n_tiles * TILE + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * blockDim.x) {
+        float o0[BPS], o1[BPS];
+        metrics(a.sym[i], o0, o1);
+#pragma unroll
+        for (int b = 0; b < BPS; ++b) {
+            if (a.soft0) a.soft0[i * BPS + b] = o0[b];
+            if (a.soft1) a.soft1[i * BPS + b] = o1[b];
         }
     }
 }
@@ -1213,32 +1306,42 @@ hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int 
 
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 4096));
-    if (a.hard) {
-        const unsigned gh = unsigned(std::min<int64_t>((a.n / 4 + 255) / 256 + 1, 4096));
-        switch (a.mod) {
-            case 1: hipLaunchKernelGGL(demap_hard_kernel<1>, dim3(gh), dim3(256), 0, s, a); break;
-            case 2: hipLaunchKernelGGL(demap_hard_kernel<2>, dim3(gh), dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL(demap_hard_kernel<4>, dim3(gh), dim3(256), 0, s, a); break;
-            case 6: hipLaunchKernelGGL(demap_hard_kernel<6>, dim3(gh), dim3(256), 0, s, a); break;
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (a.soft0 || a.soft1) {
-        if (a.mod != 2 && a.mod != 4 && a.mod != 6) return hipErrorInvalidValue;
+    const bool soft = a.soft0 || a.soft1;
+    if (soft && a.mod != 2 && a.mod != 4 && a.mod != 6) return hipErrorInvalidValue;
+    if (a.mod != 1 && a.mod != 2 && a.mod != 4 && a.mod != 6) return hipErrorInvalidValue;
+    if (soft) {
         hipError_t e = hipMemsetAsync(a.partial, 0, DEMAP_PARTIALS * sizeof(double), s);
         if (e != hipSuccess) return e;
-        const unsigned gd = unsigned(std::min<int64_t>((a.n + 255) / 256, 2048));
-        if (a.mod == 2) {
-            hipLaunchKernelGGL(demap_dmin_kernel, dim3(gd), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
-        } else if (a.mod == 4) {
-            hipLaunchKernelGGL(demap_dmin_qam_kernel<4>, dim3(gd), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(demap_soft_qam_kernel<4>, dim3(grid), dim3(256), 0, s, a);
-        } else {
-            hipLaunchKernelGGL(demap_dmin_qam_kernel<6>, dim3(gd), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(demap_soft_qam_kernel<6>, dim3(grid), dim3(256), 0, s, a);
+    }
+    // pass 1 (one read of the symbols): hard bits and / or the distance sums sigma needs
+    if (a.hard || soft) {
+        const unsigned g1 = unsigned(std::min<int64_t>((a.n / 4 + 255) / 256 + 1, 4096));
+#define OFDM_P1(M)                                                                                             \
+    do {                                                                                                       \
+        if (a.hard && soft)                                                                                    \
+            hipLaunchKernelGGL((demap_pass1_kernel<M, true, (M != 1)>), dim3(g1), dim3(256), 0, s, a);         \
+        else if (a.hard)                                                                                       \
+            hipLaunchKernelGGL((demap_pass1_kernel<M, true, false>), dim3(g1), dim3(256), 0, s, a);            \
+        else                                                                                                   \
+            hipLaunchKernelGGL((demap_pass1_kernel<M, false, (M != 1)>), dim3(g1), dim3(256), 0, s, a);        \
+    } while (0)
+        switch (a.mod) {
+            case 1: OFDM_P1(1); break;
+            case 2: OFDM_P1(2); break;
+            case 4: OFDM_P1(4); break;
+            default: OFDM_P1(6); break;
         }
+#undef OFDM_P1
+    }
+    // pass 2 (second read): the two metric arrays
+    if (soft) {
+        const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 4096));
+        if (a.mod == 2)
+            hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
+        else if (a.mod == 4)
+            hipLaunchKernelGGL(demap_soft_qam_kernel<4>, dim3(grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(demap_soft_qam64_kernel, dim3(unsigned(std::min<int64_t>(a.n / 512 + 1, 4096))), dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

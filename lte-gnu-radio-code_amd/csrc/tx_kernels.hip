@@ -178,11 +178,16 @@ __device__ __forceinline__ void tx_time_from_fft(cf (&v)[Plan<N>::P]) {
 // x (register slot order: sample m = (t + T*j) + NC*kl in x[out_slot(j,kl)]) -> CP-extended, power-normalised symbol at `o`
 // (:200-218): energy and mean over the CP-extended symbol in one pass (CP samples count twice), then one scale.
 // Two halves, so that the fused kernel can issue the next symbol's loads between them (ahead of this symbol's stores).
-template <int N>
+// RAW = true: x holds the FFT of the CONJUGATED grid row as it leaves wg_fft, i.e. N * conj(time sample).  1/N is a power of two
+// and the conjugation a sign: both are exact, so they are folded into the reductions' results and into the final scale -- the
+// staged samples stay raw and tx_cp_store applies (scale/N, -scale/N).  Every float the staged pipeline (IFFT stage: conj and
+// 1/N explicitly, then this function with RAW = false) produces is reproduced bit for bit.
+template <int N, bool RAW = false>
 __device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)[Plan<N>::P], cf* lds, float* red, int t) {
     using PL = Plan<N>;
     constexpr int T = PL::T;
     float e = 0.f, sx = 0.f, sy = 0.f;
+    const int cp0 = N - tx.cp;                                            // samples m >= cp0 appear twice (CP)
 #pragma unroll
     for (int j = 0; j < PL::C; ++j) {
 #pragma unroll
@@ -190,7 +195,16 @@ __device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)
             const int m = (t + T * j) + PL::NC * kl;
             const cf xv = x[out_slot<N>(j, kl)];
             lds[m] = xv;
-            const float w = (m >= N - tx.cp) ? 2.f : 1.f;            // CP samples appear twice
+            // a register slot holds the T consecutive samples [base, base + T): the CP weight is decided per slot on the scalar
+            // unit wherever the slot lies wholly on one side of the CP boundary (x2 and x1 are exact: same sums either way)
+            const int base = T * j + PL::NC * kl;
+            float w;
+            if (T >= 64 && base >= cp0)
+                w = 2.f;
+            else if (T >= 64 && base + T - 1 < cp0)
+                w = 1.f;
+            else
+                w = (m >= cp0) ? 2.f : 1.f;
             e += w * cnorm2(xv);
             sx += w * xv.x;
             sy += w * xv.y;
@@ -218,16 +232,26 @@ __device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)
             sy += red[w * 3 + 2];
         }
     }
-    const float Lf = float(tx.L);
-    const float a1 = (e > 1e-30f) ? sqrtf(Lf / e) : 1.f;              // :204-205
-    const float mx = a1 * sx / Lf, my = a1 * sy / Lf;
-    const float var = a1 * a1 * e / Lf - (mx * mx + my * my);         // np.var(data_time) :213
-    return a1 / sqrtf(var);                                           // :218
+    constexpr float invn = 1.f / float(N);
+    if constexpr (RAW) {
+        e *= invn * invn;
+        sx *= invn;
+        sy *= -invn;
+    }
+    // :204-218 with the hardware reciprocal square root (1 ulp; the IEEE divisions and square roots this replaces were ~60 VALU
+    // per wave and symbol):  a1 = sqrt(L / e),  out = a1 / sqrt(var)
+    const float Lf = float(tx.L), invL = 1.f / Lf;
+    const float a1 = (e > 1e-30f) ? sqrtf(Lf) * __builtin_amdgcn_rsqf(e) : 1.f;   // :204-205
+    const float mx = a1 * sx * invL, my = a1 * sy * invL;
+    const float var = a1 * a1 * e * invL - (mx * mx + my * my);           // np.var(data_time) :213
+    const float sc = a1 * __builtin_amdgcn_rsqf(var);                     // :218
+    return RAW ? sc * invn : sc;
 }
 
-template <int N>
+template <int N, bool CONJ = false>
 __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, float scale, int t, cf* o, bool active) {
     constexpr int T = Plan<N>::T;
+    const float scale_im = CONJ ? -scale : scale;
     if (active) {
         // sample j of the symbol is x[(j - cp) mod N]; with cp and L even a pair (j, j+1) never straddles the wrap: 16 B per lane
         if (((tx.cp | tx.L) & 1) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
@@ -246,9 +270,9 @@ __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, floa
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + u * T;
                     q[u].x *= scale;
-                    q[u].y *= scale;
+                    q[u].y *= scale_im;
                     q[u].z *= scale;
-                        q[u].w *= scale;
+                    q[u].w *= scale_im;
                     if (j < half) {
                         typedef float f4 __attribute__((ext_vector_type(4)));
                         __builtin_nontemporal_store(f4{q[u].x, q[u].y, q[u].z, q[u].w}, reinterpret_cast<f4*>(o4 + j));   // streamed out once
@@ -259,7 +283,7 @@ __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, floa
             for (int j = t; j < tx.L; j += T) {
                 int m = j - tx.cp;
                 if (m < 0) m += N;
-                o[j] = cscale(lds[m], scale);
+                o[j] = cf{lds[m].x * scale, lds[m].y * scale_im};
             }
         }
     }
@@ -268,8 +292,9 @@ __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, floa
 // One workgroup slot walks symbols unit, unit + stride, ...: twiddles and the pass-1 table are set up once per workgroup.
 // (Requesting the next symbol's bit words ahead of this symbol's stores -- the software pipeline of the receive kernel -- was
 // measured and bought nothing here: the kernel is VALU-issue-bound at 4 waves per SIMD, not waiting for memory.)
+constexpr int TX_LUT_ELEMS = 72;         // 64 points + the zero entry, rounded up
 template <int N, int KIND>
-__global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, ModArgs a) {
+__global__ void __launch_bounds__(Plan<N>::WG, 3) tx_modulate_kernel(TxDev tx, ModArgs a) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -281,8 +306,17 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
     float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
     const cf* w1tab = wg_init_w1<N>(smem, tx.tw, tid);
 
-    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    LaneTwiddles<N> tw;                  // all 15 pass-0 twiddles of a lane in VGPRs (the compact form costs 11 complex products per symbol)
     load_twiddles(tw, tx.tw, t);
+    // constellation table in LDS behind the pass-1 twiddles: entry e < 2^bps = conj(map_symbol(e)) (the grid row is transformed
+    // conjugated), entry 2^bps = 0 for unused bins.  One ds_read_b64 per bin replaces ~12 VALU of sign / level arithmetic.
+    cf* lut = smem + WgLds<N>::STRIDE * PL::SLOTS + WgLds<N>::W1_ELEMS;
+    const int n_pts = 1 << tx.bps;
+    for (int e = tid; e <= n_pts; e += PL::WG) {
+        const cf X = map_symbol(unsigned(e), tx.bps);
+        lut[e] = e < n_pts ? cf{X.x, -X.y} : cf{0.f, 0.f};
+    }
+    wg_barrier();                        // the table is read before the first FFT barrier
 
     const int SD = tx.S + tx.D;
     const int64_t n_units = int64_t(a.n_frames) * a.n_sym;
@@ -333,19 +367,19 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
         // half i = k - (N - K/2) for k >= N - K/2; a bin listed twice (K == N: bin N/2) keeps its later, positive-half entry
         // (the same rule as data_bin_index).  The lane's bin numbers go through an opaque copy of t: hoisted out of the symbol
         // loop, the 16 list indices and addresses cost ~100 VGPRs and the occupancy with them.
+        // Where a workgroup holds one symbol and sync symbols are copied (above), every symbol that gets here is a DATA symbol:
+        // the list indices depend on the lane only and hipcc may keep them in 16 VGPRs across the loop.  Otherwise (small
+        // sizes, handles without a finished sync symbol) the lane index passes through an opaque copy so that nothing is hoisted.
         int tt = t;
-        asm volatile("" : "+v"(tt));
+        if (!(PL::SLOTS == 1 && a.sync_time != nullptr)) asm volatile("" : "+v"(tt));
         const int hk = (is_sync ? tx.Ks : tx.Kd) >> 1;
         const int off_pos = hk - 1, off_neg = hk - N;
         int li[P];
-        float use[P];                                                     // 1 for a used bin of an active symbol, else 0
 #pragma unroll
         for (int n0 = 0; n0 < P; ++n0) {
             const int k = tt + T * n0;
             const bool pos = unsigned(k - 1) < unsigned(hk), neg = k >= N - hk;
-            const bool used = (pos || neg) && active;
-            li[n0] = used ? k + (pos ? off_pos : off_neg) : -1;
-            use[n0] = used ? 1.f : 0.f;
+            li[n0] = ((pos || neg) && active) ? k + (pos ? off_pos : off_neg) : -1;
         }
         cf v[P];
         if (is_sync) {
@@ -360,15 +394,17 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
             keep_loads(zr);
             keep_loads(zi);
 #pragma unroll
-            for (int n0 = 0; n0 < P; ++n0) v[n0] = cf{__uint_as_float(zr[n0]) * use[n0], -__uint_as_float(zi[n0]) * use[n0]};
+            for (int n0 = 0; n0 < P; ++n0) {
+                const float use = li[n0] >= 0 ? 1.f : 0.f;
+                v[n0] = cf{__uint_as_float(zr[n0]) * use, -__uint_as_float(zi[n0]) * use};
+            }
         } else if (fbits) {
             TxFetch<P, KIND> f;
             tx_fetch_issue<P, KIND>(fbits, base, li, f);
 #pragma unroll
             for (int n0 = 0; n0 < P; ++n0) {
-                // (mask by multiplication: a select around the mapping turns into a branch per bin)
-                const cf X = map_symbol(tx_fetch_value<P, KIND>(fbits, a.bits_mode, tx.bps, base, li[n0], f, n0), KIND != 0 ? (KIND & 7) : tx.bps);
-                v[n0] = cf{X.x * use[n0], -X.y * use[n0]};
+                const unsigned val = tx_fetch_value<P, KIND>(fbits, a.bits_mode, tx.bps, base, li[n0], f, n0);
+                v[n0] = lut[li[n0] >= 0 ? int(val) : n_pts];              // conj(map_symbol(val)), or 0 for an unused bin
             }
         } else {
 #pragma unroll
@@ -376,9 +412,9 @@ __global__ void __launch_bounds__(Plan<N>::WG, 4) tx_modulate_kernel(TxDev tx, M
         }
         wg_fft<N>(v, lds, tw, w1tab, t);                                         // :199
         wg_barrier();
-        tx_time_from_fft<N>(v);
-        const float scale = tx_cp_norm_stage<N>(tx, v, lds, red, t);
-        tx_cp_store<N>(tx, lds, scale, t, a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L, active);
+        // conj and 1/N of ifft(X) = conj(fft(conj(X))) / N are exact: folded into the reductions and the final scale
+        const float scale = tx_cp_norm_stage<N, true>(tx, v, lds, red, t);
+        tx_cp_store<N, true>(tx, lds, scale, t, a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L, active);
         wg_barrier();                                                            // the staged symbol has been read by every lane
     }
 }
@@ -461,7 +497,7 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_time_kernel(TxDev tx, TimeArgs
     const cf* in = a.in + (active ? row : 0) * N;
     cf v[P];
     if constexpr (DO_IFFT) {
-        std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;      // as the fused kernel: same numbers
+        LaneTwiddles<N> tw;                                                            // as the fused kernel: same numbers
         load_twiddles<N>(tw, tx.tw, t);
 #pragma unroll
         for (int n0 = 0; n0 < P; ++n0) v[n0] = active ? cconj(in[t + T * n0]) : cf{0.f, 0.f};
@@ -493,12 +529,14 @@ __global__ void __launch_bounds__(Plan<N>::WG) tx_time_kernel(TxDev tx, TimeArgs
 // SynchDataMux: S sync symbols in front of every D data symbols (symbols are L samples)
 __global__ void __launch_bounds__(256) tx_mux_kernel(TxDev tx, MuxArgs a) {
     const int L = tx.L, SD = tx.S + tx.D;
-    const int64_t s_out = blockIdx.y;
-    const int64_t pat = s_out / SD;
-    const int r = int(s_out - pat * SD);
-    const cf* src = r < tx.S ? a.sync_time + int64_t(r) * L : a.data + (pat * tx.D + (r - tx.S)) * L;
-    cf* dst = a.out + s_out * L;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < L; j += gridDim.x * blockDim.x) dst[j] = src[j];
+    // output symbols by a grid-stride loop over blockIdx.y: any pattern length and any symbol count fit one launch
+    for (int64_t s_out = blockIdx.y; s_out < a.n_out_sym; s_out += gridDim.y) {
+        const int64_t pat = s_out / SD;
+        const int r = int(s_out - pat * SD);
+        const cf* src = r < tx.S ? a.sync_time + int64_t(r) * L : a.data + (pat * tx.D + (r - tx.S)) * L;
+        cf* dst = a.out + s_out * L;
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < L; j += gridDim.x * blockDim.x) dst[j] = src[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------ channel
@@ -587,12 +625,27 @@ hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sy
     return hipGetLastError();
 }
 
-template <int N>
-static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s) {
+template <int N, int KIND>
+static hipError_t launch_mod_nk(const TxDev& tx, const ModArgs& a, hipStream_t s) {
     const int64_t units = int64_t(a.n_frames) * a.n_sym;
     const int64_t wgs = (units + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS;
-    int64_t g0 = std::min<int64_t>(wgs, 256 * 8);                          // 8 resident workgroups per CU; the rest is looped
-    if (g0 == 0) return hipSuccess;
+    if (wgs == 0) return hipSuccess;
+    const size_t lds_b = WgLds<N>::BYTES + TX_LUT_ELEMS * sizeof(cf);      // + the constellation table
+    // Exactly the workgroups that are resident at once (registers and LDS decide: asked of the runtime, once per kernel), the
+    // rest is looped: a grid larger than that runs in waves of workgroups, and the last, partly filled wave of a looping
+    // kernel costs a whole loop's time on a fraction of the chip (2 048 workgroups with 1 536 resident: +50 %).
+    static int per_cu = 0, n_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tx_modulate_kernel<N, KIND>, Plan<N>::WG, lds_b) != hipSuccess || nb < 1) nb = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1)
+            n_cu = 256;
+        else
+            n_cu = prop.multiProcessorCount;
+        per_cu = nb;
+    }
+    int64_t g0 = std::min<int64_t>(wgs, int64_t(n_cu) * per_cu);
     // a workgroup walks units first, first + stride, ...: with a stride that is a multiple of the [S, D] pattern length it would
     // meet the same position of the pattern every time (a quarter of the workgroups only copying sync symbols): keep them coprime
     if (g0 < wgs) {
@@ -600,19 +653,22 @@ static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s)
         auto gcd = [](int64_t x, int64_t y) { while (y) { const int64_t r_ = x % y; x = y; y = r_; } return x; };
         while (g0 > 1 && gcd(g0 * Plan<N>::SLOTS, SD) != 1) --g0;
     }
-    const unsigned grid = unsigned(g0);
-    const bool al4 = a.bits && ((reinterpret_cast<uintptr_t>(a.bits) | uintptr_t(a.bits_stride)) & 3) == 0;
-    const dim3 g(grid), b(Plan<N>::WG);
-    switch (tx_fetch_kind(a.bits_mode, tx.bps, al4)) {
-        case 2: hipLaunchKernelGGL((tx_modulate_kernel<N, 2>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-        case 4: hipLaunchKernelGGL((tx_modulate_kernel<N, 4>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-        case 6: hipLaunchKernelGGL((tx_modulate_kernel<N, 6>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-        case 10: hipLaunchKernelGGL((tx_modulate_kernel<N, 10>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-        case 12: hipLaunchKernelGGL((tx_modulate_kernel<N, 12>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-        case 14: hipLaunchKernelGGL((tx_modulate_kernel<N, 14>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-        default: hipLaunchKernelGGL((tx_modulate_kernel<N, 0>), g, b, WgLds<N>::BYTES, s, tx, a); break;
-    }
+    hipLaunchKernelGGL((tx_modulate_kernel<N, KIND>), dim3(unsigned(g0)), dim3(Plan<N>::WG), lds_b, s, tx, a);
     return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_mod_n(const TxDev& tx, const ModArgs& a, hipStream_t s) {
+    const bool al4 = a.bits && ((reinterpret_cast<uintptr_t>(a.bits) | uintptr_t(a.bits_stride)) & 3) == 0;
+    switch (tx_fetch_kind(a.bits_mode, tx.bps, al4)) {
+        case 2: return launch_mod_nk<N, 2>(tx, a, s);
+        case 4: return launch_mod_nk<N, 4>(tx, a, s);
+        case 6: return launch_mod_nk<N, 6>(tx, a, s);
+        case 10: return launch_mod_nk<N, 10>(tx, a, s);
+        case 12: return launch_mod_nk<N, 12>(tx, a, s);
+        case 14: return launch_mod_nk<N, 14>(tx, a, s);
+        default: return launch_mod_nk<N, 0>(tx, a, s);
+    }
 }
 
 hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s) {
@@ -682,15 +738,9 @@ hipError_t launch_tx_time(const TxDev& tx, const TimeArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_tx_mux(const TxDev& tx, const MuxArgs& a, hipStream_t s) {
-    const int SD = tx.S + tx.D;
-    const int64_t per_launch = int64_t(65535 / SD) * SD;          // blockIdx.y = output symbol, whole patterns per launch
-    for (int64_t s0 = 0; s0 < a.n_out_sym; s0 += per_launch) {
-        const int64_t cnt = std::min<int64_t>(per_launch, a.n_out_sym - s0);
-        MuxArgs b = a;
-        b.out = a.out + s0 * tx.L;
-        b.data = a.data + (s0 / SD) * tx.D * tx.L;
-        hipLaunchKernelGGL(tx_mux_kernel, dim3(unsigned((tx.L + 255) / 256), unsigned(cnt)), dim3(256), 0, s, tx, b);
-    }
+    if (a.n_out_sym <= 0) return hipSuccess;
+    const unsigned gy = unsigned(std::min<int64_t>(a.n_out_sym, 65535));
+    hipLaunchKernelGGL(tx_mux_kernel, dim3(unsigned((tx.L + 255) / 256), gy), dim3(256), 0, s, tx, a);
     return hipGetLastError();
 }
 

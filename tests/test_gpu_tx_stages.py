@@ -118,6 +118,27 @@ def test_pilots_and_flowgraph_parameters_vs_oracle(om):
         st["tx"].set_pilots([40])                    # outside the occupied span
 
 
+def test_mux_with_a_pattern_longer_than_one_launch_dimension(om):
+    """`synch_every` comes straight from the flowgraph: S + D beyond 65535 (the blockIdx.y range -- the old launcher then computed
+    a launch size of 0 and never terminated) and more output symbols than 65535 must both work."""
+    N, cp = 64, 16
+    L = N + cp
+    rng = np.random.default_rng(2)
+    for every, n_data in ((70000, 70010), (3, 90001)):
+        tx = om.TxEngine(N, cp, N - 2, 60, (1, every), "QPSK")
+        data = (rng.standard_normal((n_data, L)) + 1j * rng.standard_normal((n_data, L))).astype(np.complex64)
+        d_in = om.DeviceBuffer(data.nbytes).upload(data)
+        n_out = tx.mux_symbols(n_data)
+        d_out = om.DeviceBuffer(n_out * L * 8)
+        assert tx.mux(d_in, n_data, d_out) == n_out
+        out = d_out.download(np.complex64, n_out * L).reshape(n_out, L)
+        sync = tx.sync_symbol()[0]
+        is_sync = np.arange(n_out) % (1 + every) == 0
+        assert is_sync.sum() == n_out - n_data
+        assert np.array_equal(out[is_sync], np.broadcast_to(sync, (int(is_sync.sum()), L)))
+        assert np.array_equal(out[~is_sync], data)
+
+
 def test_random_bit_source_matches_its_definition(om):
     tx = om.TxEngine(64, 16, 62, 60)
     for seed, off, n in [(0, 0, 128), (20260101, 0, 5000), (20260101, 4097, 777), ((7 << 32) | 9, (1 << 33) + 5, 1000), (1, 127, 2)]:
