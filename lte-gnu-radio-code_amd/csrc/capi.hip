@@ -161,6 +161,8 @@ struct ofdm_rx {
     cf* d_in = nullptr;
     int64_t in_cap = 0;
     cf* d_edf = nullptr;                 // est_data_freq [num_ofdm_symb][Kd]
+    cf* d_pack = nullptr;                // the same rows without the deleted ones (:249-255), one contiguous copy to the host
+    int* pin_tsr = nullptr;              // [4] pinned host copy of s_tsr: read back without a pageable staging hop
     int* s_tsr = nullptr;                // [4]
     cf* s_H = nullptr;                   // [2][N]   rows 0 / 1 of est_chan_freq_P
     cf* s_htime = nullptr;               // [2][N]
@@ -292,7 +294,8 @@ int ofdm_device_synchronize(int32_t device) {
 int ofdm_rx_destroy(ofdm_rx* h) {
     if (!h) return OFDM_OK;
     (void)hipSetDevice(h->cfg.device);
-    void* ptrs[] = {h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
+    if (h->pin_tsr) (void)hipHostFree(h->pin_tsr);
+    void* ptrs[] = {h->d_pack, h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
                     h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime,
                     h->d_scan_g, h->d_seg_state};
     for (void* p : ptrs)
@@ -402,6 +405,9 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     auto zcp = rx_zc_lane_table(N, Ks, S, zc.data());                  // lane-order copy, stored behind the sequence itself
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM) + zcp.size());
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_edf, rows * Kd);
+    if (rc == OFDM_OK) rc = dev_alloc(&h->d_pack, rows * Kd);
+    if (rc == OFDM_OK && hipHostMalloc(reinterpret_cast<void**>(&h->pin_tsr), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+        rc = fail(OFDM_ERR_NOMEM, "pinned host allocation failed");
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_tsr, 4);
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_H, size_t(2) * N);
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_htime, size_t(2) * N);
@@ -517,7 +523,7 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
     sa.H = h->f_H;
     sa.H_for_gain = nullptr;
     sa.gain = h->f_gain;
-    sa.htime = h->f_htime;
+    sa.htime = nullptr;                  // est_chan_time is computed on demand (ofdm_rx_get_frame_state)
     sa.scan_block = h->scan_block;       // screened search where its preconditions hold (same outcome as the exhaustive one)
     sa.scan_g = h->d_scan_g;
 #ifdef OFDM_EXPERIMENTS
@@ -565,7 +571,11 @@ int ofdm_rx_get_frame_state(ofdm_rx* h, int64_t frame, float* h_chan_freq, float
     const int N = h->dev.nfft, Kd = h->dev.Kd;
     if (h_chan_freq) HIP_TRY(hipMemcpy(h_chan_freq, h->f_H + frame * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
     if (h_gain) HIP_TRY(hipMemcpy(h_gain, h->f_gain + frame * Kd, size_t(Kd) * sizeof(cf), hipMemcpyDeviceToHost));
-    if (h_chan_time) HIP_TRY(hipMemcpy(h_chan_time, h->f_htime + frame * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
+    if (h_chan_time) {                   // ifft of the frame's est_chan_freq_P row, now (SynchAndChanEst.py:202,212)
+        HIP_TRY(launch_rx_chan_time(h->dev, h->f_H + frame * N, h->f_htime + frame * N, 1, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(h_chan_time, h->f_htime + frame * N, size_t(N) * sizeof(cf), hipMemcpyDeviceToHost));
+    }
     return OFDM_OK;
 }
 
@@ -628,6 +638,97 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         // past the estimate arrays (the reference's IndexError) is left to the path below, which raises it.
         if (h->scan_block > 0 && p0 < p_valid && p_valid < (int64_t(1) << 30) && h->corr_obs + 1 < h->cfg.num_ofdm_symb) {
             const int row = h->corr_obs + 1 > 1 ? 1 : h->corr_obs + 1;
+            // ---- one-synchronisation path.  Nothing the host decides between the search and the output depends on the search's
+            // result when (a) every data row any pattern could need exists (no IndexError whatever tsr0 turns out to be), (b) the
+            // reshape of :255 and the output size are fine (both known up front): then the search, Loop B (its guard :223 is
+            // evaluated on the device against the tsr the search leaves there), the row deletion and both copies are queued
+            // back to back and the host waits ONCE.  Round 2 waited after the search, after Loop B and after the copy-out and
+            // repacked the rows on the host: 0.37-0.40 ms per 240-symbol buffer, 0.09-0.10 ms per 4-symbol buffer.
+            {
+                const int rows_ = h->cfg.num_ofdm_symb;
+                const int64_t n_pat_all = (n_unique + SD - 1) / SD;
+                const bool rows_ok = n_pat_all == 0 || (n_pat_all - 1) * SD + D - 1 < rows_;
+                int n_del_ = 0;
+                for (int r = 3; r < rows_; r += SD) ++n_del_;
+                const bool shape_ok = int64_t(rows_ - n_del_) == n_data_symb && (h->count == 0 || n_data_symb * Kd <= n_out);
+                if (rows_ok && shape_ok && h->seg_armed) {
+                    SyncArgs fa{};
+                    fa.iq = h->d_in;
+                    fa.frame_stride = n_in;
+                    fa.frame_len = n_in;
+                    fa.n_frames = 1;
+                    fa.mode = 0;
+                    fa.p_begin = int(p0);
+                    fa.p_count = int(p_valid);
+                    fa.keep_on_miss = 1;
+                    fa.scan_block = h->scan_block;
+                    fa.scan_g = h->d_scan_g;
+                    fa.seg_len = h->scan_block;
+                    fa.n_seg = int((p_valid - p0 + fa.seg_len - 1) / fa.seg_len);
+                    fa.seg_state = h->d_seg_state;
+                    fa.tsr = h->s_tsr;
+                    fa.H = h->s_H + size_t(row) * N;
+                    fa.H_for_gain = (row == 0) ? nullptr : h->s_H;                          // :242 always row 0
+                    fa.gain = h->s_gain;
+                    fa.htime = h->s_htime + size_t(row) * N;
+                    fa.esf = h->s_esf + size_t(row) * d.MM;
+                    fa.eqg = h->s_eqg;
+                    fa.yscratch = h->s_ysc;
+                    h->seg_armed = false;
+                    HIP_TRY(launch_rx_sync(d, fa, s));
+                    HIP_TRY(hipMemcpyAsync(h->pin_tsr, h->s_tsr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                    const int64_t n_dsym_all = n_pat_all * D;                               // the device applies the guard per pattern
+                    if (n_dsym_all > 0) {
+                        DemodArgs da{};
+                        da.iq = h->d_in;
+                        da.frame_stride = n_in;
+                        da.frame_len = n_in;
+                        da.n_frames = 1;
+                        da.tsr = h->s_tsr;
+                        da.gain = h->s_gain;
+                        da.eq = h->d_edf;
+                        da.mod = d.bps;
+                        da.n_dsym = int(n_dsym_all);
+                        da.row_stride_pat = SD;
+                        da.rows_per_frame = rows_;
+                        da.zero_skipped = 0;                                                // a skipped pattern keeps its old rows (:223)
+                        da.variant = h->variant;
+                        HIP_TRY(launch_rx_demod(d, da, s));
+                    }
+                    if (h->count > 0) {                                                     // :257
+                        HIP_TRY(launch_pack_rows(h->d_edf, rows_, Kd, SD, h->d_pack, s));
+                        HIP_TRY(hipMemcpyAsync(h_out, h->d_pack, size_t(n_data_symb) * Kd * sizeof(cf), hipMemcpyDeviceToHost, s));
+                    }
+                    HIP_TRY(hipStreamSynchronize(s));                                       // the one wait of this call
+                    h->seg_armed = true;
+                    const int* t4 = h->pin_tsr;
+                    if (t4[3]) {
+                        h->corr_obs += 1;                                                    // :171
+                        h->tsr[0] = t4[0];                                                   // :173-175
+                        h->tsr[1] = t4[1];
+                        h->tsr[2] = t4[2];
+                        detected = 1;
+                        trials_run = int((int64_t(t4[0]) - d.cp) / d.stride - p0 + 1);
+                    } else {
+                        trials_run = int(p_valid - p0);
+                    }
+                    if (rep) {
+                        rep->time_synch_ref[0] = h->tsr[0];
+                        rep->time_synch_ref[1] = h->tsr[1];
+                        rep->time_synch_ref[2] = h->tsr[2];
+                        rep->detected = detected;
+                        rep->trials_run = trials_run;
+                        rep->n_data_items = n_data_symb * Kd;
+                    }
+                    h->count += 1;                                                           // :260
+                    h->corr_obs = 0;                                                         // :261
+                    if (rep) {
+                        rep->count = h->count;
+                        rep->corr_obs = h->corr_obs;
+                    }
+                    return n_out;                                                            // :262
+                }
+            }
             SyncArgs fa{};
             fa.iq = h->d_in;
             fa.frame_stride = n_in;

@@ -55,6 +55,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// v of lane (i with the DPP control applied); lanes of disabled rows and lanes without a source read +inf
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_inf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// minimum over the 64 lanes of a wave, returned to every lane (same six DPP steps as wave_sum)
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, dpp_or_inf<0xB1, 0xF>(v));
+    v = fminf(v, dpp_or_inf<0x4E, 0xF>(v));
+    v = fminf(v, dpp_or_inf<0x141, 0xF>(v));
+    v = fminf(v, dpp_or_inf<0x140, 0xF>(v));
+    v = fminf(v, dpp_or_inf<0x142, 0xA>(v));
+    v = fminf(v, dpp_or_inf<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <int T>
 __device__ __forceinline__ float lanes_sum(float v) {
     if constexpr (T >= 64) {

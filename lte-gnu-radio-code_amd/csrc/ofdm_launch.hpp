@@ -131,11 +131,15 @@ struct ChanArgs {
 
 hipError_t launch_rx_demod(const RxDev& rx, const DemodArgs& a, hipStream_t s);
 hipError_t launch_rx_sync(const RxDev& rx, const SyncArgs& a, hipStream_t s);
+// htime[r] = ifft(H[r]) for n_rows rows of nfft bins (est_chan_time on demand)
+hipError_t launch_rx_chan_time(const RxDev& rx, const cf* H, cf* htime, int n_rows, hipStream_t s);
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s);
 hipError_t launch_bit_errors(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* count, hipStream_t s);
 // out[row][i] = mean_SF( in[row][SF + i*dsss] * conj(code[SF]) ), i < n_spread  (SynchEstFOAndDSSS.py:391-399)
 // rows visited in order; row r of frame f = f*D + n is divided by sqrt(mean |row f|^2) (SynchronizeAndEstimate.py:431-434)
 hipError_t launch_row_renorm(cf* eq, int Kd, int D, int n_frames, const int* tsr, hipStream_t s);
+// out = est_data_freq rows minus rows 3, 3+SD, ... (SynchAndChanEst.py:249-255), row-major
+hipError_t launch_pack_rows(const cf* edf, int rows, int Kd, int SD, cf* out, hipStream_t s);
 hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out, hipStream_t s);
 hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s);
 hipError_t launch_channel(const ChanArgs& a, hipStream_t s);

@@ -266,6 +266,38 @@ __device__ __forceinline__ void sync_finalize(const RxDev& rx, const SyncArgs& a
     }
 }
 
+// est_chan_time = ifft(est_chan_freq_P row) (:202,212) for rows of H, the same arithmetic as the finalize stage above.  The batch
+// path computes it ON DEMAND (ofdm_rx_get_frame_state) instead of once per frame and launch: one FFT and 8 N bytes per frame that
+// nothing on the data path reads.
+template <int N>
+__global__ void __launch_bounds__(Plan<N>::WG) rx_chan_time_kernel(RxDev rx, const cf* H, cf* htime, int n_rows) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T, P = PL::P;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = (T >= 64) ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
+    const int t = tid % T;
+    cf* smem = reinterpret_cast<cf*>(smem_raw);
+    cf* lds = smem + slot * WgLds<N>::STRIDE;
+    const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
+    std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, rx.tw, t);
+    const int64_t row = int64_t(blockIdx.x) * PL::SLOTS + slot;
+    const bool active = row < n_rows;
+    cf v[P];
+#pragma unroll
+    for (int n0 = 0; n0 < P; ++n0) v[n0] = active ? cconj(H[row * N + t + T * n0]) : cf{0.f, 0.f};
+    wg_fft<N>(v, lds, tw, w1tab, t);
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+            for (int kl = 0; kl < PL::RL; ++kl)
+                htime[row * N + (t + T * j) + PL::NC * kl] = cscale(cconj(v[out_slot<N>(j, kl)]), 1.f / float(N));
+        }
+    }
+}
+
 template <int N, int MINW = 3>
 __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, SyncArgs a) {
     using PL = Plan<N>;
@@ -392,17 +424,24 @@ template <int N>
 struct ScanGeom {
     static constexpr int T = Plan<N>::T;
     static constexpr int QM = (T >= 256) ? 2 : (T >= 128) ? 3 : (T >= 64) ? 4 : (T >= 32) ? 6 : (Plan<N>::P < 12 ? Plan<N>::P : 12);
-    static constexpr int BMAX = (QM * T < 256) ? QM * T : 256;        // longest block (trials per anchor)
-    static constexpr int RMAX = (BMAX + T - 1) / T;                   // window-edge samples per lane
+    static constexpr int BMAX = (QM * T < 256) ? QM * T : 256;        // longest block (trials per anchor) the recurrence walks
+    // The cold-block test (below) needs no recurrence state, only the anchor's lag vector: where one frame owns the workgroup it
+    // looks MX blocks ahead, so a frame whose sync lies far away pays one anchor per MX * B trials.
+    static constexpr int MX = (T >= 128) ? 3 : (T >= 64) ? 2 : 1;     // (two at 1024-pt: three would spill)
+    static constexpr int BX = MX * BMAX;                              // window-edge samples / thresholds held per anchor
+    static constexpr int KX = MX * QM;                                // lag values per lane the anchor keeps (alignments a < KX * T)
+    static_assert(KX <= Plan<N>::P, "the anchor's inverse FFT holds P lags per lane");
+    static constexpr int RMAX = (BX + T - 1) / T;                     // window-edge samples per lane
     static constexpr int UNR = QM >= 8 ? 1 : (QM >= 6 ? 2 : 4);       // recurrence steps per loop iteration (register budget)
-    // extra LDS per slot (cf units): dl[BMAX + 2 UNR] | xn[BMAX] | BMAX zeros, then G[0 .. QM*T] | thr[BMAX + 2 UNR floats] | flag
-    static constexpr int DL_OFF = 0, XN_OFF = BMAX + 2 * UNR, GZ_OFF = XN_OFF + BMAX, G_OFF = GZ_OFF + BMAX,
+    // extra LDS per slot (cf units): dl[BX + 2 UNR] | xn[BX] | BMAX zeros, then G[0 .. QM*T] | thr[BX + 2 UNR floats] | flag
+    static constexpr int DL_OFF = 0, XN_OFF = BX + 2 * UNR, GZ_OFF = XN_OFF + BX, G_OFF = GZ_OFF + BMAX,
                          THR_OFF = G_OFF + QM * T + 2;
-    static constexpr int FLAG_OFF = THR_OFF + (BMAX + 2 * UNR + 1) / 2;
+    static constexpr int FLAG_OFF = THR_OFF + (BX + 2 * UNR + 1) / 2;
     static constexpr int CK = 16;                                     // steps per checkpoint window (a multiple of 2 UNR)
     static constexpr int NCHK = BMAX / CK + 2;
     static constexpr int CHK_OFF = FLAG_OFF + 1;                      // tchk[NCHK floats]
-    static constexpr int EXTRA = CHK_OFF + (NCHK + 1) / 2;
+    static constexpr int BLK_OFF = CHK_OFF + (NCHK + 1) / 2;          // per wave {min thr, sum |D|} of the long and of the first block
+    static constexpr int EXTRA = BLK_OFF + 10;                        // 16 floats of block totals + 4 of first hot lags
     static constexpr size_t BYTES = WgLds<N>::BYTES + size_t(Plan<N>::SLOTS) * EXTRA * sizeof(cf);
 };
 
@@ -440,6 +479,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     float* thr = reinterpret_cast<float*>(extra + SG::THR_OFF);
     int* cflag = reinterpret_cast<int*>(extra + SG::FLAG_OFF);
     float* tchk = reinterpret_cast<float*>(extra + SG::CHK_OFF);
+    float* blk = reinterpret_cast<float*>(extra + SG::BLK_OFF);
     const float gmax = a.scan_g[N + 1].x * (1.f + 1e-5f);             // max |G[m]| (host, fp64), rounded up
 
     std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
@@ -479,7 +519,12 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
 #pragma unroll
         for (int s_ = 0; s_ < P; ++s_) Zs[s_] = cf{0.f, 0.f};
     }
-    const float gate_s = rx.gate_mm * (1.f - 1e-3f);
+    // Screening margin.  A trial is handed to the exact evaluation when its screened peak exceeds (1 - 2e-4) * gate * MM.  What the
+    // margin has to cover is the fp32 drift of the recurrence over one block -- at most 256 steps of one rounding each, 1.5e-5 of
+    // the peak if every rounding went the same way -- and the 1e-6 of the sliding energy sums: 2e-4 is ten times that.  (Round 2
+    // used 1e-3: the correlation climbs by about MM/N per trial as the window slides into the sync symbol, so a band of 1e-3 *
+    // gate * MM was ~1.4 trials wide and most frames paid an anchor for a trial that the exact evaluation then turned down.)
+    const float gate_s = rx.gate_mm * (1.f - 2e-4f);
     const float thr_k = gate_s * gate_s / float(rx.MM);                // |u|^2 > thr_k * E  <=>  p_est |u| > gate_s
 
 #ifdef OFDM_EXPERIMENTS
@@ -515,11 +560,12 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         if (!__syncthreads_or(blk_on ? 1 : 0)) break;
         SCAN_STAMP(0);
         // ---- (1) anchor: exact trial at P0
-        cf u[QM];
+        cf ux[SG::KX];                                                   // lags a = t + T*q, q < KX (the recurrence uses the first QM)
+        cf (&u)[QM] = *reinterpret_cast<cf(*)[QM]>(&ux[0]);
         float e0;
         if constexpr (SLOTS == 1) {
-            sync_trial<N, decltype(tw), QM>(rx, frame_iq, a.frame_len, blk_on, P0, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats,
-                                            ysc, nullptr, 0, u, &e0);
+            sync_trial<N, decltype(tw), SG::KX>(rx, frame_iq, a.frame_len, blk_on, P0, lds, red, tw, w1tab, t, Zs, zdups, pests, ms, dhats,
+                                                ysc, nullptr, 0, ux, &e0);
             if (ms > rx.gate_mm) {                                                      // :166 (blk_on is workgroup-uniform here)
                 found = true;
                 Phit = P0;
@@ -530,8 +576,8 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             cf zdup;
             float p_est, m;
             int dhat;
-            sync_trial<N, decltype(tw), QM>(rx, frame_iq, a.frame_len, blk_on, P0, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc,
-                                            nullptr, 0, u, &e0);
+            sync_trial<N, decltype(tw), SG::KX>(rx, frame_iq, a.frame_len, blk_on, P0, lds, red, tw, w1tab, t, Z, zdup, p_est, m, dhat, ysc,
+                                                nullptr, 0, ux, &e0);
             if (blk_on && m > rx.gate_mm) {                                             // :166
                 found = true;
                 Phit = P0;
@@ -546,17 +592,37 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         const cf y0 = cf{red[16], red[17]}, yh = cf{red[18], red[19]};
         SCAN_STAMP(1);                                                       // .. anchor trial
         // ---- (2) screen the trials P0+1 .. P0+nb-1 with the recurrence
-        const int nb = (blk_on && !found) ? min(B, nvalid - P0) : 0;      // trials of this block (incl. the anchor)
+        int nb = (blk_on && !found) ? min(B, nvalid - P0) : 0;            // trials of this block (incl. the anchor)
+        int nbx = (blk_on && !found) ? min(SG::MX * B, nvalid - P0) : 0;   // ... of the long block the cold test looks over
         int cand = 0x7fffffff;
         if (__syncthreads_or(nb > 1 ? 1 : 0)) {
-            // window edges: xo[i] = x[w0 + i], xn[i] = x[w0 + N + i], w0 = P0 + cp;  i < nb - 1
+            if constexpr (SG::MX > 1) {
+                // How far ahead is the long block worth looking?  From far away the sync symbol already shows in the anchor's lag
+                // vector at the alignments that will see it whole (the cp + 1 lags before its own): the long block ends where the
+                // first lag at half the anchor's own threshold would come within reach (a <= n - 1 + cp), so that the cold test
+                // below has a chance over all of it.  Only the amount of work depends on this guess, never a decision.
+                float ah = 3.0e38f;
+                const float half2 = 0.25f * thr_k * e0;
+#pragma unroll
+                for (int q = 0; q < SG::KX; ++q)
+                    if (!(cnorm2(ux[q]) < half2)) ah = fminf(ah, float(t + T * q));
+                ah = wave_min(ah);
+                if ((t & 63) == 0) blk[16 + (t >> 6)] = ah;
+                wg_barrier();
+#pragma unroll
+                for (int w = 0; w < (T + 63) / 64; ++w) ah = fminf(ah, blk[16 + w]);
+                const int a_first = ah < 1.0e9f ? int(ah) : 0x3fffffff;
+                nbx = max(nb, min(nbx, a_first - cp));
+                wg_barrier();                                            // blk[16..] is read by everyone before the next anchor rewrites it
+            }
+            // window edges: xo[i] = x[w0 + i], xn[i] = x[w0 + N + i], w0 = P0 + cp;  i < nbx - 1
             const int64_t w0 = int64_t(P0) + cp;
             float dw = 0.f, wadd = 0.f;
             cf da = cf{0.f, 0.f}, db = cf{0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < SG::RMAX; ++r) {
                 const int i = t * SG::RMAX + r;                          // contiguous chunk per lane
-                if (i < nb - 1) {
+                if (i < nbx - 1) {
                     const cf o = frame_iq[w0 + i], n_ = frame_iq[w0 + N + i];
                     xo[i] = o;
                     xn[i] = n_;
@@ -617,10 +683,12 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             // anchor: E_0 = e0 (in band), N W_0 = e0 + |Y[0]|^2 + |Y[N/2]|^2, sum x = Y[0], sum (-1)^n x = Y[N/2]
             const float nw0 = e0 + cnorm2(y0) + cnorm2(yh);
             const float wbound = nw0 + float(N) * tot_add;               // >= N W_j for every j of the block
+            // this lane's share of {min_j thr_j, sum_i |D_i|} of the long block (x) and of its first block (b)
+            float my_tmin = 3.0e38f, my_dabs = 0.f, my_tminb = 3.0e38f, my_dabsb = 0.f;
 #pragma unroll
             for (int r = 0; r < SG::RMAX; ++r) {
                 const int i = t * SG::RMAX + r;
-                if (i < nb - 1) {
+                if (i < nbx - 1) {
                     const cf o = xo[i], n_ = xn[i];
                     const float sgn = (i & 1) ? 1.f : -1.f;
                     pw += cnorm2(n_) - cnorm2(o);
@@ -631,17 +699,72 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     const float ej = nwj - cnorm2(y0 + pa) - cnorm2(yh + pb);
                     // too little energy left for the sliding sums to be trusted -> force an exact evaluation
                     const bool weak = !(nwj > 1e-4f * wbound) || !(ej > 1e-3f * nwj);
-                    thr[i + 1] = weak ? -1.f : thr_k * ej;
+                    const float th_ = weak ? -1.f : thr_k * ej;
+                    thr[i + 1] = th_;
                     xo[i] = n_ - o;                                      // dl[i] (this lane's own entry)
+                    const float dm = sqrtf(cnorm2(n_ - o));
+                    my_tmin = fminf(my_tmin, th_);
+                    my_dabs += dm;
+                    if (i < nb - 1) {
+                        my_tminb = fminf(my_tminb, th_);
+                        my_dabsb += dm;
+                    }
                 }
             }
-            // padding read by the unrolled loop past the block's last step: adds nothing, never flags
-            for (int idx = t; idx < SG::BMAX + 2 * SG::UNR; idx += T) {
-                if (idx >= nb - 1) xo[idx] = cf{0.f, 0.f};
-                if (idx >= nb) thr[idx] = 3.0e38f;
+            if constexpr (SLOTS == 1) {
+                my_tmin = wave_min(my_tmin);
+                my_dabs = wave_sum(my_dabs);
+                my_tminb = wave_min(my_tminb);
+                my_dabsb = wave_sum(my_dabsb);
+                if ((t & 63) == 0) {
+                    float* b4 = blk + (t >> 6) * 4;
+                    b4[0] = my_tmin;
+                    b4[1] = my_dabs;
+                    b4[2] = my_tminb;
+                    b4[3] = my_dabsb;
+                }
             }
-            if (t == 0) *cflag = 0x7fffffff;
-            wg_barrier();
+            // Cold blocks.  c_{P0+j}[d] = c_{P0}[d + j] + sum_{i<j} D_i G[.] exactly, so over a WHOLE block no correlation value can
+            // rise above |u_a(0)| + max|G| * sum_i |D_i|.  Where that stays below the block's lowest threshold for every alignment
+            // the block can reach (a <= n - 1 + cp), no trial of the block can be flagged -- let alone accepted: the thresholds sit
+            // 2e-4 below the gate -- and the block is skipped WITHOUT running the recurrence.  The test needs nothing but the
+            // anchor's lag vector, so it is made over MX blocks first (one anchor per MX * B trials far from the sync) and, if
+            // that fails, over the first block alone.  Weak-energy trials (thr < 0) and blocks near the sync fail both and take
+            // the screened recurrence below, exactly as before.
+            bool run_block = true;
+            if constexpr (SLOTS == 1) {
+                wg_barrier();                                            // blk[] and the thresholds are written
+                auto cold = [&](int which, int n_tr) {
+                    float tmin_b = 3.0e38f, dtot = 0.f;
+#pragma unroll
+                    for (int w = 0; w < (T + 63) / 64; ++w) {
+                        tmin_b = fminf(tmin_b, blk[w * 4 + 2 * which]);
+                        dtot += blk[w * 4 + 2 * which + 1];
+                    }
+                    const float room = sqrtf(fmaxf(tmin_b, 0.f)) - dtot * gmax * (1.f + 1e-5f);
+                    bool hot = !(tmin_b > 0.f) || !(room > 0.f);
+                    const float lim2 = room * room * (1.f - 1e-5f);
+#pragma unroll
+                    for (int q = 0; q < SG::KX; ++q) hot |= (t + T * q <= n_tr - 1 + cp) && !(cnorm2(ux[q]) < lim2);
+                    return __syncthreads_or(hot ? 1 : 0) == 0;
+                };
+                if (nbx > nb && cold(0, nbx)) {
+                    nb = nbx;                                            // the long block is cold: skip all of it
+                    run_block = false;
+                } else if (cold(1, nb)) {
+                    run_block = false;
+                }
+            }
+            if (run_block) {
+                // padding read by the unrolled loop past the block's last step: adds nothing, never flags
+                for (int idx = t; idx < SG::BMAX + 2 * SG::UNR; idx += T) {
+                    if (idx >= nb - 1) xo[idx] = cf{0.f, 0.f};
+                    if (idx >= nb) thr[idx] = 3.0e38f;
+                }
+                if (t == 0) *cflag = 0x7fffffff;
+                wg_barrier();
+            }
+            if (run_block) {
             // Checkpoints.  Window c = steps c CK + 1 .. (c+1) CK.  One step changes a correlation value by D_j G[.], at most
             // |D_j| max|G|, so no value can pass its threshold inside the window unless it starts the window within
             // sum |D| max|G| of the window's lowest threshold: |u|^2 > tchk[c] = (sqrt(min thr) - sum|D| max|G|)^2 is tested
@@ -761,6 +884,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                 cand = c2;
                 wg_barrier();
             }
+            }   // run_block
         }
         // the first flagged trial is the next anchor (evaluated exactly there); an unflagged block is skipped whole
         if (nb > 0) P0 += (cand < nb) ? cand : nb;
@@ -1165,6 +1289,23 @@ __global__ void __launch_bounds__(256) row_renorm_kernel(cf* eq, int Kd, int D, 
     }
 }
 
+// ------------------------------------------------------------------------------------------ output packing of the stream block
+// SynchAndChanEst.py:249-255: rows 3, 3 + (S+D), ... of est_data_freq are deleted (literal 3), the rest flattened row-major.
+// Done on the device so that the block's output leaves in ONE contiguous device-to-host copy straight into the caller's buffer.
+__global__ void __launch_bounds__(256) pack_rows_kernel(const cf* edf, int rows, int Kd, int SD, cf* out) {
+    const int r = blockIdx.y;
+    if (r >= 3 && (r - 3) % SD == 0) return;                                            // a deleted row
+    const int w = r - (r >= 3 ? (r - 3) / SD + 1 : 0);                                  // rows kept before it
+    const float4* src = reinterpret_cast<const float4*>(edf + int64_t(r) * Kd);         // Kd is even: whole 16 B pairs
+    float4* dst = reinterpret_cast<float4*>(out + int64_t(w) * Kd);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (Kd >> 1); i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_pack_rows(const cf* edf, int rows, int Kd, int SD, cf* out, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(unsigned(((Kd >> 1) + 255) / 256), unsigned(rows)), dim3(256), 0, s, edf, rows, Kd, SD, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ DSSS despreading
 __global__ void despread_kernel(const cf* in, int in_row_stride, const cf* code, int dsss, int n_spread, int rows, cf* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1302,6 +1443,26 @@ hipError_t launch_despread(const cf* in, int in_row_stride, const cf* code, int 
     hipLaunchKernelGGL(despread_kernel, dim3(unsigned((n_spread + 63) / 64), unsigned(rows)), dim3(64), 0, s, in, in_row_stride, code,
                        dsss, n_spread, rows, out);
     return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_chan_time_n(const RxDev& rx, const cf* H, cf* htime, int n_rows, hipStream_t s) {
+    const unsigned grid = unsigned((n_rows + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+    hipLaunchKernelGGL(rx_chan_time_kernel<N>, dim3(grid), dim3(Plan<N>::WG), WgLds<N>::BYTES, s, rx, H, htime, n_rows);
+    return hipGetLastError();
+}
+hipError_t launch_rx_chan_time(const RxDev& rx, const cf* H, cf* htime, int n_rows, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    switch (rx.nfft) {
+        case 64: return launch_chan_time_n<64>(rx, H, htime, n_rows, s);
+        case 128: return launch_chan_time_n<128>(rx, H, htime, n_rows, s);
+        case 256: return launch_chan_time_n<256>(rx, H, htime, n_rows, s);
+        case 512: return launch_chan_time_n<512>(rx, H, htime, n_rows, s);
+        case 1024: return launch_chan_time_n<1024>(rx, H, htime, n_rows, s);
+        case 2048: return launch_chan_time_n<2048>(rx, H, htime, n_rows, s);
+        case 4096: return launch_chan_time_n<4096>(rx, H, htime, n_rows, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
