@@ -321,6 +321,9 @@ def main(argv=None):
     ap.add_argument("--sync-search", default="screened", choices=["screened", "exhaustive"],
                     help="exhaustive: the reference's trial-by-trial sync search (A/B against the screened search; same outputs)")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the N-rank control flow on CPU/gloo (tests); no GPU work")
+    ap.add_argument("--contention-probe", action="store_true",
+                    help="N = 1 only, after the timed loop: the same steps again while a second stream moves what an 8-GPU all-gather "
+                         "would put on this GPU's HBM (7 x the step's packed bits written, the same amount read); untimed for `value`")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -608,11 +611,52 @@ def main(argv=None):
         roof = dict(bound="hbm", kernel="rx_demod_kernel<%d>" % N, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=int(alg), kernel_ms=round(dm, 4), sync_kernel_ms=round(float(k_sync), 4),
+                    kernel_source_sha=sha,
                     stream_read_only_frac=round(dsym * L * 8 / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     physical_read_GBs=None if phys_read is None else round(phys_read, 1),
                     measured_copy_GBs=None if copy_gbs is None else round(copy_gbs, 1),
                     access_pattern_no_math_GBs=None if pat_gbs is None else round(pat_gbs, 1),
                     package_power_w_and_sclk_mhz_under_load=power)
+        contention = None
+        if world == 1 and args.contention_probe:
+            # What the re-assembly would cost the HBM-bound demod at N = 8, measured on one GPU: per step every rank receives 7 x its
+            # own packed bits into its receive buffer (HBM writes) and its own shard is read by 7 peers (HBM reads).  A device copy
+            # of that size on a second stream reads and writes exactly that much while the step runs.
+            nbytes = int(d_bits.numel()) * 7
+            src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            side = torch.cuda.Stream(device=device)
+            k3 = max(20, min(args.steps, 100))
+
+            def timed(mode):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k3):
+                    if mode:
+                        with torch.cuda.stream(side):
+                            if mode == 1:
+                                dst.copy_(src, non_blocking=True)        # 7 shards written AND 7 shards read (peers reading ours)
+                            else:
+                                dst.fill_(1)                             # the inbound writes alone
+                    step()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / k3 * 1e3
+            timed(1)
+            a0, a1, b1, a2, a3, b3 = timed(0), timed(1), timed(2), timed(0), timed(1), timed(2)
+            wo, wi, ww = min(a0, a2), min(a1, a3), min(b1, b3)
+            contention = dict(what="step with a concurrent device copy of 7 x the step's packed bits (all-gather traffic of N = 8 on this GPU's HBM)",
+                              bytes_written_and_read_per_step=nbytes, steps=k3, ms_per_step_without=round(wo, 4), ms_per_step_with=round(wi, 4),
+                              slowdown=round(wi / wo, 4), ms_per_step_with_writes_only=round(ww, 4), slowdown_writes_only=round(ww / wo, 4),
+                              copy_GBs_if_alone=None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src, non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            contention["copy_GBs_if_alone"] = round(2 * nbytes * 10 / e0.elapsed_time(e1) / 1e6, 1)
+            del src, dst
         cpu = None
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(cfg, inputs[0][0], fl)
@@ -629,7 +673,7 @@ def main(argv=None):
                        # frame are never fetched (BASELINE.md's "HBM-read roofline" definition); roofline.physical_read_GBs is fetched bytes
                        "stream_equivalent_read_fraction_of_8TBs": round(value * 1e6 * 8 / world / 8e12, 4),
                        "bit_error_rate_frame0": ber, "sync_search": sync_mode, "all_gather": gather_info,
-                       "resident_plan_GB_per_gpu": round(need / 1e9, 1)},
+                       "resident_plan_GB_per_gpu": round(need / 1e9, 1), "hbm_contention_probe": contention},
             "roofline": roof, "cpu_baseline": cpu,
         }
     if dist is not None:

@@ -349,6 +349,9 @@ def _decision_margin(z, mod):
     return np.minimum(dr, di)
 
 
+CFG3_BER_SEED99 = 0.041454   # gpurun_out/r03y/fullsize.log: 4369 frames, seed 99, 64-QAM, per-frame Rayleigh taps, 30 dB
+
+
 @pytest.mark.parametrize("config", ["cfg2", "cfg3"])
 def test_full_size_batch_properties(om, config):
     """BASELINE.json's full sizes (config 2: 4369 frames x 240 symbols = 1,048,560 symbols, 16-QAM, AWGN; config 3: 64-QAM
@@ -360,7 +363,7 @@ def test_full_size_batch_properties(om, config):
     import torch
     import bench
     cfg = dict(bench.CONFIGS[config])
-    n_frames = cfg["frames"] if config == "cfg2" else 1024
+    n_frames = cfg["frames"]                                   # both configs at BASELINE's 4369 frames (1,048,560 symbols)
     N, cp, Kd, mod, n_sym = cfg["nfft"], cfg["cp"], cfg["Kd"], cfg["mod"], cfg["n_sym"]
     fl = n_sym * (N + cp)
     torch.cuda.set_device(0)
@@ -402,7 +405,12 @@ def test_full_size_batch_properties(om, config):
     else:
         lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int32, device="cuda")
         nerr = sum(int(lut[(b1[f0:f0 + 128] ^ tx_bits[f0:f0 + 128]).long()].sum().item()) for f0 in range(0, n_frames, 128))
-        assert nerr / (b1.numel() * 8) < 0.1                               # informational: deep fades at 64-QAM do err (~3 %)
+        # 64-QAM under 8-tap Rayleigh fading with a one-tap equaliser does err in the faded bins.  Inputs, taps and noise are seeded
+        # and every kernel is deterministic, so the batch's bit error rate is a fixed number: pinned to the value of the first run
+        # of this test (round 3), with room only for a different chip's transcendentals in the noise generator.
+        ber = nerr / (b1.numel() * 8)
+        print("config 3 bit error rate over %d frames: %.6f" % (n_frames, ber))
+        assert abs(ber - CFG3_BER_SEED99) < 3e-4, ber
     eq2, b2 = run(d_rx)
     assert torch.equal(b1, b2) and torch.equal(eq1, eq2)                   # (ii)
     w = torch.arange(1, nbytes + 1, device="cuda", dtype=torch.int64) % 251

@@ -14,6 +14,8 @@ for CFG in "$@"; do
   # figure the bench line reports and not dominated by the first launches after an idle GPU (5.4, 5.3, 5.0, 4.7 ms ... at cfg2)
   rm -rf $OUT/kt
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --config $CFG --no-cpu --no-probes > $OUT/kt.json 2> $OUT/kt.err)
+  # the plain bench line of the same build (no profiler attached): what profiles/<tag>_bench_<config>.json is made from
+  python3 $R/bench.py --config $CFG --no-cpu > $OUT/bench.json 2> $OUT/bench.err
   if [ "${ONLY_KT:-0}" = "1" ]; then echo "$CFG: $(tail -c 300 $OUT/kt.json | head -c 300)"; continue; fi
   (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err)
   (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.json 2> $OUT/write.err)

@@ -45,6 +45,17 @@ def main():
         ks = sorted(glob.glob(os.path.join(base, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
         shutil.copy(ks, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
         line = json.loads(open(os.path.join(base, "kt.json")).read().strip().splitlines()[-1])
+        # the plain bench line is committed only if it was produced by the sources that are in the tree now
+        bpath = os.path.join(base, "bench.json")
+        if os.path.exists(bpath):
+            bl = json.loads(open(bpath).read().strip().splitlines()[-1])
+            got = bl["roofline"].get("kernel_source_sha")
+            if got != sha:
+                raise SystemExit("%s: bench line of kernel sources %s, the tree is %s -- re-run tools/run_profiles.sh" % (bpath, got, sha))
+            with open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (tag, cfg)), "w") as f:
+                f.write(json.dumps(bl) + "\n")
+        if line["roofline"].get("kernel_source_sha") != sha:
+            raise SystemExit("%s/kt.json was measured on kernel sources %s, the tree is %s" % (base, line["roofline"].get("kernel_source_sha"), sha))
         fe, wr = pmc(os.path.join(base, "fetch"), "FETCH_SIZE"), pmc(os.path.join(base, "write"), "WRITE_SIZE")
         name = [k for k in fe if "rx_demod_kernel" in k][0]
         c = bench.CONFIGS[cfg]
