@@ -808,7 +808,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         // into LDS once per chunk; >= 20 rounds of resident workgroups at the bench sizes keep the tail short).
         const int trips = (a.n_dsym + DG::NS - 1) / DG::NS;
         const int64_t total_trips = int64_t(a.n_frames) * trips;
-        constexpr int per_chunk = N >= 2048 ? 32 : 20;                      // symbols per chunk aimed at (A/B: 30 at 2048-pt, 18 at 1024-pt)
+        constexpr int per_chunk = N == 2048 ? 32 : 20;                      // symbols per chunk aimed at (A/B: 30 at 2048-pt, 18-20 at 1024- and 4096-pt)
         int want = int(std::max<int64_t>(1, (int64_t(trips) * DG::NS + per_chunk - 1) / per_chunk));
         if (total_trips / std::max(want, 1) < 4096) want = int(std::max<int64_t>(1, std::min<int64_t>(trips, 4096 / std::max(a.n_frames, 1))));  // few frames: finer
 #ifdef OFDM_TUNE_ENV     // study builds only (make geom GEOMFLAGS=-DOFDM_TUNE_ENV): chunk count per frame from the environment
