@@ -184,6 +184,8 @@ struct ofdm_rx {
     int scan_block = 0;                  // > 0: the batch path's sync search is screened in blocks of this many trials
     cf* d_scan_g = nullptr;              // [N + 2] recurrence kernel G, then {max |G|, 0}
     int* d_seg_state = nullptr;          // [2] {first hit, segments done} of the stream block's segment-parallel search
+    unsigned* d_work = nullptr;          // [2] work queue of the batch demod launch {next chunk, workgroups done}
+    bool use_queue = true;
     bool seg_armed = false;              // the kernel re-arms the two words itself; false after a launch that did not complete
     int variant = 0;
     unsigned* d_stamps = nullptr;
@@ -297,7 +299,7 @@ int ofdm_rx_destroy(ofdm_rx* h) {
     if (h->pin_tsr) (void)hipHostFree(h->pin_tsr);
     void* ptrs[] = {h->d_pack, h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
                     h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime,
-                    h->d_scan_g, h->d_seg_state};
+                    h->d_scan_g, h->d_seg_state, h->d_work};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev)
@@ -443,6 +445,17 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
 #ifdef OFDM_EXPERIMENTS
     if (const char* ev = std::getenv("OFDM_EXP_VARIANT")) h->variant = std::atoi(ev);   // run a whole test suite on one variant
 #endif
+    {   // work queue of the batch demod launch: two words, zero between launches (the kernel re-arms them itself)
+        int rcq = dev_alloc(&h->d_work, 2);
+        if (rcq == OFDM_OK && hipMemset(h->d_work, 0, 2 * sizeof(unsigned)) != hipSuccess) rcq = fail(OFDM_ERR_HIP, "work queue init failed");
+        if (rcq != OFDM_OK) {
+            std::string keep = g_last_error;
+            ofdm_rx_destroy(h);
+            g_last_error = keep;
+            return rcq;
+        }
+        if (const char* e = std::getenv("OFDM_MI355X_DEMOD_QUEUE")) h->use_queue = std::atoi(e) != 0;   // 0: one chunk per workgroup (A/B)
+    }
     h->scan_block = rx_sync_scan_block(d);
     if (h->scan_block > 0) {
         auto g = make_scan_table(N, Ks, zc);
@@ -554,6 +567,7 @@ int64_t ofdm_rx_demod_frames(ofdm_rx* h, const float* d_iq, int64_t n_frames, in
         da.zero_skipped = 1;
         da.variant = h->variant;
         da.stamps = h->d_stamps;
+        da.work = h->use_queue ? h->d_work : nullptr;
         HIP_TRY(launch_rx_demod(d, da, s));
     }
     if (h->profiling) {

@@ -29,6 +29,7 @@ struct DemodArgs {
     unsigned* stamps;        // diagnostic variant 9: [workgroups][waves][8] phase cycle sums, or null
     const cf* rot;           // per-sample rotator e^{j 2pi fo n/fs} [nfft] applied to every window (CFO receiver), or null
     int host_guard;          // 1: a frame is demodulated iff tsr[frame][3] != 0 (the host applied the reference's own guard)
+    unsigned* work;          // [2] device words {next chunk, workgroups done}, both 0 between launches: work queue (batch path), or null
 };
 
 // ---- RX sync search + LS estimate (reference: SynchAndChanEst.py:143-219, "Loop A") -----------

@@ -33,6 +33,9 @@
 #ifndef OFDM_FLAGS_T128
 #define OFDM_FLAGS_T128 0u      // DemodFlags of that kernel
 #endif
+#ifndef OFDM_FLAGS_T256
+#define OFDM_FLAGS_T256 0u      // ... and of the 4096-pt kernel (a symbol owned by 256 lanes)
+#endif
 #ifndef OFDM_LANE_TW
 #define OFDM_LANE_TW 1          // 1: all 15 pass-0 twiddles of a lane in VGPRs (30) instead of 4 base values + 11 products per symbol
 #endif
@@ -344,7 +347,8 @@ struct DemodGeom {
     static constexpr int NS = (T >= 256) ? 1 : (T >= 128) ? OFDM_NS_T128 : (T >= 64 ? 2 : 64 / T);
     static constexpr int WG = T * NS;
     static constexpr int W1_OFF = WgLds<N>::STRIDE * NS;                    // cf units
-    static constexpr int G_OFF = W1_OFF + WgLds<N>::W1_ELEMS;
+    static constexpr int Q_OFF = W1_OFF + WgLds<N>::W1_ELEMS;               // 2 cf: the work-queue slot
+    static constexpr int G_OFF = Q_OFF + 2;
     static size_t lds_bytes(int Kd, bool glds) { return (size_t(G_OFF) + (glds ? ((Kd + 3) & ~3) : 0)) * sizeof(cf); }
 };
 
@@ -403,8 +407,36 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     }
     const cf* w1tab = w1w;
 
-    // one chunk (a run of symbols of ONE frame) per workgroup
-    const int64_t chunk = blockIdx.x;
+    std::conditional_t<CT, CompactTwiddles<N>, LaneTwiddles<N>> tw;
+    load_twiddles(tw, rx.tw, t);
+
+    // STAMP (diagnostic build only, never timed): cycles per phase, summed over the chunk, one row per wave
+    unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            unsigned long long tn;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn)::"memory");
+            acc[i] += unsigned(tn - tprev);
+            tprev = tn;
+        }
+    };
+    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+    // A chunk is a run of symbols of ONE frame.  Without a work queue (a.work == nullptr: stream blocks, small launches) workgroup
+    // b owns chunk b.  With one, the launch has only as many workgroups as are resident at once and each takes chunk after chunk
+    // from an atomic counter until the launch's chunks are used up: twiddles and the pass-1 table are set up once per workgroup
+    // instead of once per chunk, and the CUs -- and the XCDs, whose share of a plain launch is fixed by the round-robin dispatch --
+    // stay busy until the queue is empty instead of until their own last chunk is done.  The exit condition is reached by every
+    // workgroup: the counter only grows.
+    const int64_t n_chunks = int64_t(a.n_frames) * a.chunks_per_frame;
+    int* const qslot = reinterpret_cast<int*>(smem + DG::Q_OFF);          // one LDS word: the chunk the workgroup works on
+    int64_t chunk = blockIdx.x;
+    if (a.work) {
+        if (tid == 0) *qslot = int(atomicAdd(a.work, 1u));
+        __syncthreads();
+        chunk = *qslot;
+    }
+    for (; chunk < n_chunks;) {
     const int frame = int(chunk / a.chunks_per_frame);
     const int cidx = int(chunk % a.chunks_per_frame);
     // Balanced partition of the frame's data symbols into chunks_per_frame runs of whole trips (NS symbols): lengths differ by at
@@ -413,9 +445,6 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
     const int ds0 = int(int64_t(cidx) * trips / a.chunks_per_frame) * NS;
     const int ds1 = min(int(int64_t(cidx + 1) * trips / a.chunks_per_frame) * NS, a.n_dsym);
     constexpr bool active = true;
-
-    std::conditional_t<CT, CompactTwiddles<N>, LaneTwiddles<N>> tw;
-    load_twiddles(tw, rx.tw, t);
 
     const int Kd = rx.Kd, L = rx.L, S = rx.S, D = rx.D;
     const int tsr0 = a.tsr[frame * 4 + 0];
@@ -444,18 +473,6 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
 
     const float sqrt_kd = sqrtf(float(Kd));
     const int n_iter = (ds1 - ds0 + NS - 1) / NS;                         // trips of THIS chunk
-    // STAMP (diagnostic build only, never timed): cycles per phase, summed over the chunk, one row per wave
-    unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = 0;
-    auto stamp = [&](int i) {
-        if constexpr (STAMP) {
-            unsigned long long tn;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn)::"memory");
-            acc[i] += unsigned(tn - tprev);
-            tprev = tn;
-        }
-    };
-    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
     // Per-symbol bookkeeping (uniform per slot).  SynchAndChanEst.py:222-223: data_ptr = tsr0 + S*L*(P+1), P = p*(S+D),
     // guarded once per pattern; :226: CP strip by offset.
     struct Sym {
@@ -782,6 +799,20 @@ __global__ void __launch_bounds__(DemodGeom<N>::WG, MINW) rx_demod_kernel(RxDev 
         slot_sync<WL>();                                                 // staging region free for the next symbol
         stamp(7);                                                        // .. loop-end barrier
     }
+    if (!a.work) break;
+    // next chunk: every wave is done with the LDS of this one (gain copy, staging) before the slot word and the gains change
+    __syncthreads();
+    if (tid == 0) *qslot = int(atomicAdd(a.work, 1u));
+    __syncthreads();
+    chunk = *qslot;
+    }   // chunks
+    if (a.work) {
+        // the last workgroup to leave re-arms the two words for the next launch (every fetch of this launch lies before its own exit)
+        if (tid == 0 && atomicAdd(a.work + 1, 1u) == gridDim.x - 1) {
+            atomicExch(a.work, 0u);
+            atomicExch(a.work + 1, 0u);
+        }
+    }
     if constexpr (STAMP) {
         if ((tid & 63) == 0 && a.stamps) {
             unsigned* o = a.stamps + (int64_t(blockIdx.x) * (DG::WG / 64) + (tid >> 6)) * 8;
@@ -804,11 +835,13 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         // the short chunk of every frame landed on XCDs 3 and 7, the others carried 6.7 % more than the average, and the
         // kernel took 5.5 % longer than with equal chunks (profiles/r03_demod_chunking.txt).  So: (1) chunks of EQUAL length
         // where the frame's trips divide evenly, (2) else lengths that differ by one trip with an ODD chunk count per frame,
-        // so that every XCD sees every chunk index equally often; 20-32 symbols per chunk (the frame's gains are copied
+        // so that every XCD sees every chunk index equally often; 12-20 symbols per chunk (the frame's gains are copied
         // into LDS once per chunk; >= 20 rounds of resident workgroups at the bench sizes keep the tail short).
         const int trips = (a.n_dsym + DG::NS - 1) / DG::NS;
         const int64_t total_trips = int64_t(a.n_frames) * trips;
-        constexpr int per_chunk = N == 2048 ? 32 : 20;                      // symbols per chunk aimed at (A/B: 30 at 2048-pt, 18-20 at 1024- and 4096-pt)
+        // symbols per chunk aimed at.  A/B with the work queue on (profiles/r03_demod_chunking.txt): 9-10 chunks per 180-symbol frame
+        // at 2048-pt, 12-15 at 4096-pt, 15 at 1024-pt (without the queue, where twiddles and tables are set up per chunk: 6 / 9 / 9)
+        constexpr int per_chunk = N == 2048 ? 20 : N >= 4096 ? 14 : 12;
         int want = int(std::max<int64_t>(1, (int64_t(trips) * DG::NS + per_chunk - 1) / per_chunk));
         if (total_trips / std::max(want, 1) < 4096) want = int(std::max<int64_t>(1, std::min<int64_t>(trips, 4096 / std::max(a.n_frames, 1))));  // few frames: finer
 #ifdef OFDM_TUNE_ENV     // study builds only (make geom GEOMFLAGS=-DOFDM_TUNE_ENV): chunk count per frame from the environment
@@ -827,8 +860,9 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         a.chunks_per_frame = best;
         a.spc = ((trips + best - 1) / best) * DG::NS;                       // longest chunk (informational)
     }
-    const unsigned grid = unsigned(int64_t(a.n_frames) * a.chunks_per_frame);
-    size_t lds = DG::lds_bytes(rx.Kd, !(Plan<N>::T == 128 && (OFDM_FLAGS_T128 & (DF_GAINS_GLOBAL | DF_GAINS_VGPR))));
+    unsigned grid = unsigned(int64_t(a.n_frames) * a.chunks_per_frame);
+    size_t lds = DG::lds_bytes(rx.Kd, !((Plan<N>::T == 128 && (OFDM_FLAGS_T128 & (DF_GAINS_GLOBAL | DF_GAINS_VGPR))) ||
+                                        (Plan<N>::T == 256 && (OFDM_FLAGS_T256 & (DF_GAINS_GLOBAL | DF_GAINS_VGPR)))));
 #ifdef OFDM_EXPERIMENTS
     if (a.variant >= 100) lds += size_t(a.variant - 100) * 1024;   // occupancy experiment: pad the LDS request by (variant-100) KiB
 #endif
@@ -886,7 +920,7 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     }
 #endif
     constexpr int MW = (Plan<N>::T == 128) ? OFDM_MINW_T128 : 3;
-    constexpr unsigned FL = (Plan<N>::T == 128) ? OFDM_FLAGS_T128 : 0u;
+    constexpr unsigned FL = (Plan<N>::T == 128) ? OFDM_FLAGS_T128 : (Plan<N>::T == 256) ? OFDM_FLAGS_T256 : 0u;
     // more than 64 KB of dynamic LDS per workgroup (4 slots at 2048-pt) has to be announced once per kernel
 #define OFDM_LD(M, B)                                                                                                        \
     do {                                                                                                                     \
@@ -897,6 +931,25 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         }                                                                                                                    \
         hipLaunchKernelGGL((rx_demod_kernel<N, M, B, MW, FL>), dim3(grid), dim3(DG::WG), lds, s, rx, a);                     \
     } while (0)
+    if (a.work) {
+        // work queue: the resident workgroups only (occupancy of the 16-QAM packed instantiation stands for all of them: the
+        // register counts of the MOD / BMODE variants differ by a few VGPRs inside one occupancy step; the queue itself is
+        // correct with any grid size)
+        static int per_cu = 0, n_cu = 0;
+        if (per_cu == 0) {
+            int nb = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_demod_kernel<N, 4, 1, MW, FL>, DG::WG, lds) != hipSuccess || nb < 1) nb = 2;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                       ? prop.multiProcessorCount : 256;
+            per_cu = nb;
+        }
+        const int64_t resident = int64_t(per_cu) * n_cu;
+        if (int64_t(grid) > 2 * resident)
+            grid = unsigned(resident);
+        else
+            a.work = nullptr;                     // not worth a queue: one chunk per workgroup
+    }
 #define OFDM_LD_MOD(B)                  \
     switch (a.mod) {                    \
         case 1: OFDM_LD(1, B); break;   \

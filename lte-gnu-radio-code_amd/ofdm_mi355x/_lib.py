@@ -150,14 +150,21 @@ def _mapped_hip_runtimes():
 
 
 def _pin_hip_runtime():
-    """One HIP runtime per process, whatever the import order.
+    """One HIP runtime per process, whatever the import order -- and torch's device code registered BEFORE that runtime starts.
 
     libofdm_mi355x.so needs `libamdhip64.so.7`; the PyTorch-ROCm wheel ships its own library under the SAME soname.  The
     dynamic linker keeps whichever was mapped first for both users.  The system runtime first and torch second leaves torch
     on a runtime it was not built for (`RuntimeError: No HIP GPUs are available` on the first torch.cuda call); torch's
-    runtime first works for both.  So: when torch is installed (found WITHOUT importing it) and no HIP runtime is mapped yet,
-    map torch's bundled runtime first.  Hosts without torch (GNU Radio, the C example) get the system runtime.
-    OFDM_MI355X_SYSTEM_HIP=1 opts out."""
+    runtime first works for both.
+
+    Mapping torch's runtime first is not enough, though (round 3, `profiles/r03_import_order_library_first_STUCK.log`): when this
+    library has INITIALISED the runtime and `import torch` comes afterwards, `from torch._C import *` (torch/__init__.py) loads
+    ~1 GB of shared objects whose constructors register their device code with a runtime that is already live -- it is unpacked on
+    the spot instead of lazily.  That takes 6-8 s on a good day and was caught sitting there for 150 s (the watchdog's stack dump).
+    So when torch is installed and not imported yet, it is imported HERE, before anything touches the GPU: its device code is
+    registered lazily, as in every torch-first program (about 1.5 s once per process).  OFDM_MI355X_NO_TORCH_IMPORT=1 keeps torch
+    out (then only its runtime is mapped first, as before); OFDM_MI355X_SYSTEM_HIP=1 opts out of both.  Hosts without torch
+    (GNU Radio, the C example) get the system runtime."""
     global hip_runtime_path
     mapped = _mapped_hip_runtimes()
     if mapped:
@@ -173,6 +180,17 @@ def _pin_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
+    if "torch" not in sys.modules and os.environ.get("OFDM_MI355X_NO_TORCH_IMPORT") != "1":
+        _trace("importing torch before the HIP runtime starts")
+        try:
+            import importlib
+            importlib.import_module("torch")
+        except Exception as e:                              # a broken torch install must not take this library down with it
+            _trace("import torch failed (%s: %s): mapping its runtime only" % (type(e).__name__, e))
+        mapped = _mapped_hip_runtimes()
+        if mapped:
+            hip_runtime_path = mapped[0]
+            return
     cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(cand):
         try:

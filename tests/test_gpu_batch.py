@@ -461,7 +461,12 @@ def test_count_bit_errors_equals_numpy(om, n, off_a, off_b):
 
 
 @pytest.mark.parametrize("N,cp,Ks,Kd,mod", [(1024, 72, 1022, 602, "QPSK"), (2048, 144, 2046, 1198, "16QAM"), (4096, 288, 4094, 2402, "64QAM"),
-                                             (1024, 72, 1024, 1024, "16QAM")])
+                                             (1024, 72, 1024, 1024, "16QAM"),
+                                             # list edges ON register-slot / 128-entry block boundaries, nearly empty and nearly full lists:
+                                             # the scalar "slot wholly listed / wholly unlisted / block inside Kd" decisions of the kernel
+                                             (2048, 144, 2046, 1024, "16QAM"), (2048, 144, 2046, 256, "QPSK"), (2048, 144, 2046, 2044, "64QAM"),
+                                             (2048, 144, 2046, 1280, "16QAM"), (1024, 72, 1022, 128, "16QAM"), (1024, 72, 1022, 1020, "QPSK"),
+                                             (4096, 288, 4094, 512, "16QAM"), (4096, 288, 4094, 4092, "QPSK"), (4096, 288, 4094, 2048, "64QAM")])
 def test_dense_output_mapping_on_awkward_bin_counts(om, N, cp, Ks, Kd, mod):
     """From 1024-pt up a lane of the demod kernel owns two PAIRS of list entries 128 apart and bits leave in groups of four
     entries assembled across a lane pair.  Bin counts that are even but not a multiple of 4 (the last pair of a row has no

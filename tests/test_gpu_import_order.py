@@ -2,12 +2,13 @@
 used to leave torch with `RuntimeError: No HIP GPUs are available`).  Each order runs ONCE in a fresh interpreter.
 
 Round 2 saw the library-first child overrun 300 s once in ~25 suite runs and hid it behind a retry without keeping the child's
-output.  What reading the link lines excludes: in BOTH orders exactly one libamdhip64 / libhsa-runtime64 /
-libamd_comgr is mapped, all from torch/lib (libofdm_mi355x.so needs only the soname libamdhip64.so.7, which torch's copy already
-satisfies; torch's copy resolves its own dependencies through RPATH=$ORIGIN) -- so not "two runtimes in one process".  What is
-left is unknown, therefore there is NO second attempt any more: every child stamps each stage on stderr, carries a watchdog that
-dumps all thread stacks (faulthandler) well before the parent's timeout, its stderr is written to gpurun_out/ on every run,
-and an overrun FAILS the test with that record attached."""
+output.  Round 3 removed the retry, gave the children stage stamps and a faulthandler watchdog -- and caught it
+(profiles/r03_import_order_library_first_STUCK.log): the child sat in `from torch._C import *`, i.e. in the dlopen of torch's
+~1 GB of shared objects, whose constructors register their device code with a HIP runtime this library had ALREADY initialised
+(unpacked on the spot instead of lazily: 6-8 s normally, 150+ s that time).  `_lib.load()` therefore imports torch itself, before
+anything touches the GPU, whenever torch is installed: "library first" is torch first underneath.  The third case keeps the old
+order alive on purpose (OFDM_MI355X_NO_TORCH_IMPORT=1) but only checks what can be checked without importing torch afterwards.
+There is still NO second attempt: stage stamps, watchdog, the record under gpurun_out/ on every run, and an overrun FAILS."""
 import os
 import subprocess
 import sys
@@ -39,7 +40,8 @@ import ofdm_mi355x as om
 stage("ofdm_mi355x imported")
 om.load()
 stage("library loaded")
-rx = om.RxEngine(8, 64, 16, 62, (1, 3), 60, 100)          # touches the GPU through the library BEFORE torch is imported
+assert "torch" in sys.modules                             # load() imported it: its device code is registered before the runtime starts
+rx = om.RxEngine(8, 64, 16, 62, (1, 3), 60, 100)          # touches the GPU through the library before the PROGRAM imports torch
 stage("ofdm_rx_create returned (first HIP initialisation of this process)")
 buf = om.DeviceBuffer(64).upload(np.arange(16, dtype=np.float32))
 stage("device buffer uploaded")
@@ -88,7 +90,25 @@ def _keep_record(name, text):
         pass
 
 
-@pytest.mark.parametrize("name,code", [("library-first", LIB_FIRST), ("torch-first", TORCH_FIRST)], ids=["library-first", "torch-first"])
+LIB_ONLY = PRELUDE + """
+os.environ["OFDM_MI355X_NO_TORCH_IMPORT"] = "1"
+import numpy as np
+import ofdm_mi355x as om
+om.load()
+stage("library loaded without importing torch")
+assert "torch" not in sys.modules
+rx = om.RxEngine(8, 64, 16, 62, (1, 3), 60, 100)
+stage("ofdm_rx_create returned")
+from ofdm_mi355x import _lib
+assert len(_lib._mapped_hip_runtimes()) == 1
+print("ok", _lib.hip_runtime_path, flush=True)
+rx.close()
+stage("handle released; leaving the interpreter")
+"""
+
+
+@pytest.mark.parametrize("name,code", [("library-first", LIB_FIRST), ("torch-first", TORCH_FIRST), ("library-only", LIB_ONLY)],
+                         ids=["library-first", "torch-first", "library-only"])
 def test_either_import_order_works(name, code):
     try:
         r = subprocess.run([sys.executable, "-c", code % (ROOT, PKG)], capture_output=True, text=True, timeout=TIMEOUT_S)
