@@ -26,6 +26,9 @@
 #ifndef OFDM_B_SWZ_RL8
 #define OFDM_B_SWZ_RL8 0
 #endif
+#ifndef OFDM_W1_COMPACT_RL8
+#define OFDM_W1_COMPACT_RL8 0      // 2048-pt geometry study: the 4-entry pass-1 twiddle rows of the 4096-pt plan (256 B instead of 1 KB)
+#endif
 
 namespace ofdm {
 
@@ -162,7 +165,7 @@ struct Plan {
     static constexpr bool B_SWZ = THREE && (RL == 16 || (RL == 8 && OFDM_B_SWZ_RL8 != 0));
     static constexpr int LDS_B = B_SWZ ? NC * RL : NC * (RL + 1);   // exchange B elements
     // pass-1 twiddle table: all 15 powers per n2 (16*RL entries), or only W^1, W^2, W^4, W^8 (4*RL entries, 4096-pt: LDS again)
-    static constexpr bool W1_COMPACT = THREE && RL == 16;
+    static constexpr bool W1_COMPACT = THREE && (RL == 16 || (RL == 8 && OFDM_W1_COMPACT_RL8 != 0));
     static constexpr int W1_ELEMS = THREE ? (W1_COMPACT ? 4 * RL : 16 * RL) : 0;
     static constexpr int LDS_ELEMS = (LDS_A > LDS_B ? LDS_A : LDS_B) > N ? (LDS_A > LDS_B ? LDS_A : LDS_B) : N;
     static constexpr int SLOTS = (T >= 64) ? 1 : 64 / T;   // symbols handled side by side in one workgroup
