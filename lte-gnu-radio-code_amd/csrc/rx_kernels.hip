@@ -12,6 +12,10 @@
 // its Kd equalised bins (+ packed bits).  No MFMA: the path is FFT + elementwise, HBM-bound.
 #include "rx_demod.hpp"
 
+#ifndef OFDM_SCAN_MINW
+#define OFDM_SCAN_MINW 2        // waves per SIMD the screened sync search is compiled for (3: a 168-VGPR budget)
+#endif
+
 namespace ofdm {
 
 // ------------------------------------------------------------------------------------------ sync
@@ -1341,10 +1345,10 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
         if (a.n_seg > 0) {
             if (a.n_frames != 1 || a.seg_len <= 0 || !a.seg_state) return hipErrorInvalidValue;
             const unsigned gseg = unsigned((int64_t(a.n_seg) + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
-            hipLaunchKernelGGL((rx_sync_scan_kernel<N, 2, true>), dim3(gseg), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
+            hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(gseg), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL((rx_sync_scan_kernel<N, 2>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
+        hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
         return hipGetLastError();
     }
     // 3 waves per SIMD (168 VGPRs, a few spills off the trial path): 0.14 ms instead of 0.21 ms per 4369-frame launch; the

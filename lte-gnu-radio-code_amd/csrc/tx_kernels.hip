@@ -292,9 +292,12 @@ __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, floa
 // One workgroup slot walks symbols unit, unit + stride, ...: twiddles and the pass-1 table are set up once per workgroup.
 // (Requesting the next symbol's bit words ahead of this symbol's stores -- the software pipeline of the receive kernel -- was
 // measured and bought nothing here: the kernel is VALU-issue-bound at 4 waves per SIMD, not waiting for memory.)
+#ifndef OFDM_TX_MINW
+#define OFDM_TX_MINW 3          // waves per SIMD the fused transmit kernel is compiled for (4: a 128-VGPR budget; A/B in DESIGN.md 4.3)
+#endif
 constexpr int TX_LUT_ELEMS = 72;         // 64 points + the zero entry, rounded up
 template <int N, int KIND>
-__global__ void __launch_bounds__(Plan<N>::WG, 3) tx_modulate_kernel(TxDev tx, ModArgs a) {
+__global__ void __launch_bounds__(Plan<N>::WG, OFDM_TX_MINW) tx_modulate_kernel(TxDev tx, ModArgs a) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
