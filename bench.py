@@ -259,7 +259,7 @@ def dry_launch_rank(args, world, rank):
     batches = cfg.get("batches", 1)
     bounds = od.sub_batches(n_frames * batches, max(args.chunks if world > 1 else 1, batches))
     pipe = od.GatherPipeline(dist if world > 1 else None, torch, world, bounds, n_frames * batches, row_bytes, "cpu",
-                             generations=1 if batches > 1 else 2)
+                             generations=1 if batches > 1 else 2, algo="direct" if args.gather == "direct" else "collective", rank=rank)
 
     def produce(bits, f0, f1):
         bits[f0:f1] = (torch.arange(f0, f1, dtype=torch.int64)[:, None] * 7 + rank * 31 + torch.arange(row_bytes)[None, :]).to(torch.uint8)
@@ -320,6 +320,10 @@ def main(argv=None):
                          "at a different trial) | <int> (the same lead for every frame; kernel studies)")
     ap.add_argument("--sync-search", default="screened", choices=["screened", "exhaustive"],
                     help="exhaustive: the reference's trial-by-trial sync search (A/B against the screened search; same outputs)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "collective", "direct"],
+                    help="N > 1: re-assembly of the packed bits as one collective (all_gather_into_tensor), as a group of point-to-point "
+                         "transfers (one per xGMI link and direction), or whichever of the two an untimed calibration before the timed "
+                         "loop finds faster on this node (default)")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the N-rank control flow on CPU/gloo (tests); no GPU work")
     ap.add_argument("--contention-probe", action="store_true",
                     help="N = 1 only, after the timed loop: the same steps again while a second stream moves what an 8-GPU all-gather "
@@ -439,7 +443,37 @@ def main(argv=None):
     # generation is enough -- the gather of batch b has the other batches' demod time before its buffers come round again.
     pipe = od.GatherPipeline(dist, torch, world, bounds, n_frames * batches, bytes_per_frame_bits, "cuda",
                              recv_device="cpu" if rehearsal else "cuda", host_staging=rehearsal,
-                             generations=1 if batches > 1 else 2, gather_at_world_1=force_dist)
+                             generations=1 if batches > 1 else 2, gather_at_world_1=force_dist,
+                             algo="direct" if args.gather == "direct" else "collective", rank=rank)
+    # --gather auto: which spelling of the re-assembly is faster is a property of the node (RCCL's all-gather algorithm against
+    # 2(W-1) point-to-point transfers, one per link and direction).  Both are run on the first sub-batch's buffers before anything
+    # is timed, every rank contributes its slower time, and the faster form is used for the timed loop.  A failure of the
+    # point-to-point form on this node simply leaves the collective in place.
+    gather_calibration = None
+    if multi and pipe.gather and args.gather == "auto":
+        try:
+            f0, f1 = bounds[0]
+            src = pipe.bits[0][f0:f1].cpu() if rehearsal else pipe.bits[0][f0:f1].contiguous()
+            src.zero_()
+            times = {}
+            for algo in ("collective", "direct"):
+                pipe.algo = algo
+                for it in range(5):
+                    if it == 2:
+                        torch.cuda.synchronize()
+                        dist.barrier()
+                        t_c = time.perf_counter()
+                    pipe.gather_rows(pipe.recv[0][0], src).wait()
+                torch.cuda.synchronize()
+                tt = torch.tensor([(time.perf_counter() - t_c) / 3 * 1e3], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                times[algo] = float(tt.item())
+            pipe.algo = "direct" if times["direct"] < 0.97 * times["collective"] else "collective"
+            gather_calibration = dict(collective_ms=round(times["collective"], 4), direct_ms=round(times["direct"], 4), chosen=pipe.algo,
+                                      bytes_per_rank=int(src.numel()))
+        except Exception as e:
+            pipe.algo = "collective"
+            gather_calibration = dict(error="%s: %s" % (type(e).__name__, e), chosen="collective")
 
     def produce(bits, r0, r1):
         b, f0 = divmod(r0, n_frames)
@@ -507,7 +541,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         tg = time.perf_counter()
         for _ in range(5):
-            dist.all_gather_into_tensor(gathered[0], src)
+            pipe.gather_rows(gathered[0], src).wait()
         torch.cuda.synchronize()
         g_ms = (time.perf_counter() - tg) / 5 * 1e3
         nb = src.numel()
@@ -548,7 +582,7 @@ def main(argv=None):
                                bit_errors_all_ranks=int(tot.item()), bits_all_ranks=int(d_bits.numel()) * 8 * world)
         except Exception as e:                      # never lose the measured line to the extra leg
             counts_only = dict(error="%s: %s" % (type(e).__name__, e))
-        gather_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
+        gather_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), algorithm=pipe.algo, calibration=gather_calibration,
                            rccl_version=_rccl_version(torch) if not rehearsal else None,
                            bytes_contributed_per_rank_and_step=int(d_bits.numel()), bytes_received_per_rank_and_step=int(d_bits.numel() * (world - 1)),
                            allgather_alone_ms=round(g_ms, 4), allgather_alone_busbw_GBs=round(nb * (world - 1) / (g_ms * 1e-3) / 1e9, 2),

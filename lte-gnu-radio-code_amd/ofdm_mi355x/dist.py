@@ -2,7 +2,8 @@
 
 Frames are independent (each is one reference work() buffer: own sync, own channel estimate), so rank r simply owns
 frames [r*n/W, (r+1)*n/W) and there is no data-path collective.  The only exchange is the all-gather of the packed hard
-bits (RCCL over xGMI on GPUs; gloo in the CPU tests), issued per sub-batch so that it overlaps the demod of the next one.
+bits (RCCL over xGMI on GPUs; gloo in the CPU tests), issued per sub-batch so that it overlaps the demod of the next one --
+as one collective (`all_gather_into_tensor`) or as a group of point-to-point transfers (`direct_gather_bits`).
 """
 from __future__ import annotations
 
@@ -34,6 +35,37 @@ def all_gather_bits(dist, recv, local_bits, f0: int, f1: int, async_op: bool = T
     return dist.all_gather_into_tensor(recv, local_bits[f0:f1].contiguous(), async_op=async_op)
 
 
+class _WorkGroup:
+    """The works of one grouped point-to-point exchange behind the `wait()` of a single collective's work handle."""
+
+    def __init__(self, works, keep=None):
+        self.works = list(works or [])
+        self.keep = keep                     # the source tensor stays alive until the exchange is waited for
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def direct_gather_bits(dist, recv, src, rank: int, world: int):
+    """The same re-assembly as `all_gather_bits`, spelled as point-to-point transfers: every rank sends its rows to each of its
+    W-1 peers and receives each peer's rows straight into its place in `recv` ([world*rows, row_bytes], rank-major); its own
+    rows are a local copy.  One group of 2(W-1) transfers (`batch_isend_irecv`: one ncclGroup under RCCL), peers visited at
+    distance 1, 2, ... so that at every distance each rank talks to a different pair.  On a node whose GPUs are fully connected
+    by point-to-point xGMI links this puts ONE transfer per direction on every link and takes one hop -- which
+    form is faster on a given node is a measurement: `bench.py --gather auto` times both before the timed loop and keeps the
+    faster.  Returns a handle with `wait()`."""
+    rows = src.shape[0]
+    slots = recv.view(world, rows, recv.shape[1])
+    slots[rank].copy_(src, non_blocking=True)
+    ops = []
+    for k in range(1, world):
+        to, frm = (rank + k) % world, (rank - k) % world
+        ops.append(dist.P2POp(dist.isend, src, to))
+        ops.append(dist.P2POp(dist.irecv, slots[frm], frm))
+    return _WorkGroup(dist.batch_isend_irecv(ops) if ops else [], keep=src)
+
+
 def reassemble(torch, recv_list, world: int):
     """[world, n_frames, row_bytes] copy of the whole bit-stream from the per-sub-batch receive buffers."""
     return torch.cat([r.view(world, r.shape[0] // world, r.shape[1]) for r in recv_list], dim=1)
@@ -49,8 +81,11 @@ class GatherPipeline:
     (gloo rehearsal of the control flow on a box with fewer GPUs than ranks)."""
 
     def __init__(self, dist, torch, world, bounds, n_rows, row_bytes, device, recv_device=None, generations=2, host_staging=False,
-                 gather_at_world_1=False):
+                 gather_at_world_1=False, algo="collective", rank=0):
         self.dist, self.torch, self.world, self.bounds = dist, torch, world, list(bounds)
+        if algo not in ("collective", "direct"):
+            raise ValueError("algo must be 'collective' (all_gather_into_tensor) or 'direct' (grouped point-to-point transfers)")
+        self.algo, self.rank = algo, rank
         # a one-rank group still runs the collectives when asked to (the only way to exercise the RCCL calls on a 1-GPU box)
         self.gather = world > 1 or (gather_at_world_1 and dist is not None)
         self.gen = generations if self.gather else 1
@@ -73,8 +108,14 @@ class GatherPipeline:
             produce(bits, f0, f1)
             if self.gather:
                 src = bits[f0:f1].cpu() if self.host_staging else bits[f0:f1].contiguous()
-                self.pending[g][ci] = self.dist.all_gather_into_tensor(self.recv[g][ci], src, async_op=True)
+                self.pending[g][ci] = self.gather_rows(self.recv[g][ci], src)
         self.steps += 1
+
+    def gather_rows(self, recv, src):
+        """Start the re-assembly of one sub-batch (asynchronous; returns a handle with wait())."""
+        if self.algo == "direct":
+            return direct_gather_bits(self.dist, recv, src, self.rank, self.world)
+        return self.dist.all_gather_into_tensor(recv, src, async_op=True)
 
     def drain(self):
         for row in self.pending:

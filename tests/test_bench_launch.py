@@ -23,9 +23,9 @@ def _run(*args, env=None, timeout=300):
     return subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=env or _env())
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
-def test_gpus_2_spawns_two_ranks(cfg):
-    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch", "--config", cfg)
+@pytest.mark.parametrize("cfg,gather", [("cfg2", "auto"), ("cfg4", "auto"), ("cfg2", "direct"), ("cfg4", "direct")])
+def test_gpus_2_spawns_two_ranks(cfg, gather):
+    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch", "--config", cfg, "--gather", gather)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout

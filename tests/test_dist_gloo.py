@@ -84,7 +84,7 @@ def test_shard_helpers():
     assert od.sub_batches(2, 4) == [(0, 1), (1, 2)]
 
 
-def _pipeline_worker(rank, world, port, q):
+def _pipeline_worker(rank, world, port, q, algo="collective"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "lte-gnu-radio-code_amd")]
@@ -94,7 +94,7 @@ def _pipeline_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_rows, row_bytes, steps = 11, 96, 5
     bounds = od.sub_batches(n_rows, 4)
-    pipe = od.GatherPipeline(dist, torch, world, bounds, n_rows, row_bytes, "cpu")
+    pipe = od.GatherPipeline(dist, torch, world, bounds, n_rows, row_bytes, "cpu", algo=algo, rank=rank)
     history = []
 
     def make(step):
@@ -115,14 +115,15 @@ def _pipeline_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_pipeline_two_generations():
-    """The step loop bench.py runs at N > 1 (GatherPipeline: per sub-batch produce + async all-gather, two buffer generations,
-    deferred waits, drain) with 2 gloo ranks on CPU: after 5 steps every rank holds both ranks' rows of the LAST step."""
-    world = 2
+@pytest.mark.parametrize("world,algo", [(2, "collective"), (2, "direct"), (3, "direct")])
+def test_two_rank_gather_pipeline_two_generations(world, algo):
+    """The step loop bench.py runs at N > 1 (GatherPipeline: per sub-batch produce + async re-assembly, two buffer generations,
+    deferred waits, drain) with gloo ranks on CPU: after 5 steps every rank holds every rank's rows of the LAST step -- with the
+    re-assembly as one collective and as a group of point-to-point transfers (three ranks: two peers per rank)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
