@@ -2,7 +2,7 @@
 """bench.py -- IQ Msamples/s through the RX hot path (sync + LS estimate + CP strip + FFT + equalise + de-map)
 on MI355X, with the kernel's HBM roofline fraction and a same-box CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfgA|n1024|n4096] [--lead random]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfgA|n128|n256|n512|n1024|n4096] [--lead random]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: before anything touches the
 GPU it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child and
@@ -51,6 +51,12 @@ CONFIGS = {
     # configs[0] shape (the reference's own CPU-runnable case), scaled up in frame count
     "cfgA": dict(nfft=64, cp=16, Kd=60, mod="QPSK", n_sym=240, frames=65536, chan="ref5tap", snr_db=100.0,
                  name="64-pt FFT / 16-CP / Kd=60 / QPSK, reference 5-tap channel"),
+    "n128": dict(nfft=128, cp=9, Kd=72, mod="16QAM", n_sym=240, frames=32768, chan="awgn", snr_db=30.0,
+                 name="128-pt FFT / 9-CP / Kd=72 / 16-QAM, AWGN"),
+    "n256": dict(nfft=256, cp=18, Kd=180, mod="16QAM", n_sym=240, frames=16384, chan="awgn", snr_db=30.0,
+                 name="256-pt FFT / 18-CP / Kd=180 / 16-QAM, AWGN"),
+    "n512": dict(nfft=512, cp=36, Kd=300, mod="16QAM", n_sym=240, frames=16384, chan="awgn", snr_db=30.0,
+                 name="512-pt FFT / 36-CP / Kd=300 / 16-QAM, AWGN"),
     "n1024": dict(nfft=1024, cp=72, Kd=600, mod="16QAM", n_sym=240, frames=8738, chan="awgn", snr_db=30.0,
                   name="1024-pt FFT / 72-CP / Kd=600 / 16-QAM, AWGN"),
     "n4096": dict(nfft=4096, cp=288, Kd=2400, mod="16QAM", n_sym=240, frames=2184, chan="awgn", snr_db=30.0,

@@ -18,6 +18,7 @@
 // MINW  __launch_bounds__ min waves per SIMD (register budget; 3 -> 168 VGPRs)
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -841,7 +842,9 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
         const int64_t total_trips = int64_t(a.n_frames) * trips;
         // symbols per chunk aimed at.  A/B with the work queue on (profiles/r03_demod_chunking.txt): 9-10 chunks per 180-symbol frame
         // at 2048-pt, 12-15 at 4096-pt, 15 at 1024-pt (without the queue, where twiddles and tables are set up per chunk: 6 / 9 / 9)
-        constexpr int per_chunk = N == 2048 ? 20 : N >= 4096 ? 14 : 12;
+        // Below 1024-pt a symbol is a few hundred bytes and a trip a few microseconds: a chunk is at least ~128 KB of input there
+        // (a whole 180-symbol frame at 64-pt), or the per-chunk costs (queue, gain copy, unpipelined first loads) take over.
+        const int per_chunk = N == 2048 ? 20 : N >= 4096 ? 14 : N == 1024 ? 12 : std::max(12, 131072 / (rx.L * 8));
         int want = int(std::max<int64_t>(1, (int64_t(trips) * DG::NS + per_chunk - 1) / per_chunk));
         if (total_trips / std::max(want, 1) < 4096) want = int(std::max<int64_t>(1, std::min<int64_t>(trips, 4096 / std::max(a.n_frames, 1))));  // few frames: finer
 #ifdef OFDM_TUNE_ENV     // study builds only (make geom GEOMFLAGS=-DOFDM_TUNE_ENV): chunk count per frame from the environment
@@ -924,13 +927,18 @@ hipError_t launch_rx_demod_n(const RxDev& rx, const DemodArgs& a_in, hipStream_t
     // more than 64 KB of dynamic LDS per workgroup (4 slots at 2048-pt) has to be announced once per kernel
 #define OFDM_LD(M, B)                                                                                                        \
     do {                                                                                                                     \
-        if (lds > 65536) {                                                                                                   \
-            static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_demod_kernel<N, M, B, MW, FL>),   \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));             \
-            if (once != hipSuccess) return once;                                                                             \
+        static std::atomic<int> announced{65536};          /* grows with Kd (gain table): announce every new maximum */      \
+        if (int(lds) > announced.load(std::memory_order_relaxed)) {                                                          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_demod_kernel<N, M, B, MW, FL>),             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                       \
+            if (e != hipSuccess) return e;                                                                                   \
+            announced.store(int(lds), std::memory_order_relaxed);                                                            \
         }                                                                                                                    \
         hipLaunchKernelGGL((rx_demod_kernel<N, M, B, MW, FL>), dim3(grid), dim3(DG::WG), lds, s, rx, a);                     \
     } while (0)
+    // below 1024-pt a chunk is a whole frame or a large part of one and the static grid measured 1-5 % ahead of the queue
+    // (profiles/r03_small_sizes.txt)
+    if (N < 1024) a.work = nullptr;
     if (a.work) {
         // work queue: the resident workgroups only (occupancy of the 16-QAM packed instantiation stands for all of them: the
         // register counts of the MOD / BMODE variants differ by a few VGPRs inside one occupancy step; the queue itself is

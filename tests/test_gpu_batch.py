@@ -503,3 +503,26 @@ def test_dense_output_mapping_on_awkward_bin_counts(om, N, cp, Ks, Kd, mod):
     else:
         with pytest.raises(ValueError):
             rx.demod_frames(d_iq, n_frames, fl, fl, None, om.DeviceBuffer(n_frames * nds * Kd * bps // 8 + 8), om.BITS_PACKED, None)
+
+
+def test_lds_request_grows_with_the_bin_count_inside_one_process(om):
+    """The demod kernel's LDS request includes the per-frame gain table (Kd entries): at 4096-pt it crosses 64 KB, which has to be
+    announced per kernel -- and announced AGAIN when a later engine asks for more (ascending Kd, same instantiation)."""
+    N, cp, Ks, mod, n_sym = 4096, 288, 4094, "16QAM", 8
+    L = N + cp
+    for Kd in (3600, 3840, 4092):
+        rng = np.random.default_rng(Kd)
+        tx = orc.tx_modulate(rng.integers(0, 2, (n_sym // 4) * 3 * Kd * 4), N, cp, Ks, Kd, n_sym, modulation=mod)
+        iq = orc.channel_apply(tx, orc.REF_TAPS, N)[:n_sym * L + cp + 3][None, :].astype(np.complex64)
+        fl = iq.shape[1]
+        rx = om.RxEngine(n_sym, N, cp, Ks, (1, 3), Kd, 100, 0.7, modulation=mod)
+        nds = rx.data_symbols_per_frame(fl)
+        d_iq = om.DeviceBuffer(iq.nbytes).upload(iq)
+        d_eq = om.DeviceBuffer(nds * Kd * 8)
+        d_bp = om.DeviceBuffer(nds * Kd * 4 // 8)
+        assert rx.demod_frames(d_iq, 1, fl, fl, d_eq, d_bp, om.BITS_PACKED, None) == nds
+        eq = d_eq.download(np.complex64, nds * Kd).reshape(nds, Kd)
+        o = orc.RxOracle(n_sym, N, cp, Ks, [1, 3], Kd, 100, 0.7, force_fp64=True)
+        o.work(iq[0], np.zeros(fl, np.complex64))
+        assert_close(eq, o.est_data_freq[[r for r in range(n_sym) if r % 4 != 3]], "Kd %d" % Kd)
+        assert np.array_equal(np.unpackbits(d_bp.download(np.uint8, nds * Kd * 4 // 8)), orc.demap_hard(eq.ravel(), mod))
