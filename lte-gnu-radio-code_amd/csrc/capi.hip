@@ -151,6 +151,8 @@ int fill_rxdev(const ofdm_rx_cfg& cfg, RxDev& d) {
 struct ofdm_rx {
     ofdm_rx_cfg cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;       // stream block: the first stage of the sync search runs here, under the rest of the upload
+    hipEvent_t ev_up = nullptr, ev_s1 = nullptr;
     RxDev dev{};
     cf* d_tw = nullptr;
     cf* d_zc = nullptr;
@@ -162,7 +164,16 @@ struct ofdm_rx {
     int64_t in_cap = 0;
     cf* d_edf = nullptr;                 // est_data_freq [num_ofdm_symb][Kd]
     cf* d_pack = nullptr;                // the same rows without the deleted ones (:249-255), one contiguous copy to the host
-    int* pin_tsr = nullptr;              // [4] pinned host copy of s_tsr: read back without a pageable staging hop
+    int* pin_tsr = nullptr;              // [4] pinned host copy of s_tsr, written by the search kernel itself (tsr_host)
+    int* pin_tsr_dev = nullptr;          //     its device address
+    // GNU Radio sized buffers (a few symbols): a copy in the stream costs more than it moves (5-10 us of engine latency plus a
+    // 10-20 us bubble next to the kernels), so buffers up to PIN_BYTES go through pinned host memory that the kernels read and
+    // write in place over the link; the host's share is a memcpy of a few tens of KB
+    static constexpr size_t PIN_BYTES = size_t(256) << 10;
+    cf* pin_in = nullptr;
+    cf* pin_in_dev = nullptr;
+    cf* pin_out = nullptr;
+    cf* pin_out_dev = nullptr;
     int* s_tsr = nullptr;                // [4]
     cf* s_H = nullptr;                   // [2][N]   rows 0 / 1 of est_chan_freq_P
     cf* s_htime = nullptr;               // [2][N]
@@ -297,6 +308,8 @@ int ofdm_rx_destroy(ofdm_rx* h) {
     if (!h) return OFDM_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->pin_tsr) (void)hipHostFree(h->pin_tsr);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     void* ptrs[] = {h->d_pack, h->d_tw,    h->d_zc,  h->d_in,  h->d_edf,     h->s_tsr,     h->s_H,       h->s_htime, h->s_esf, h->s_eqg,
                     h->s_gain,  h->s_ysc, h->d_trial_m, h->d_trial_d, h->d_partial, h->f_tsr, h->f_H, h->f_gain, h->f_htime,
                     h->d_scan_g, h->d_seg_state, h->d_work};
@@ -304,6 +317,9 @@ int ofdm_rx_destroy(ofdm_rx* h) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
+    if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return OFDM_OK;
@@ -399,6 +415,10 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     if (e != hipSuccess) {
         rc = fail(OFDM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (rc == OFDM_OK && (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_s1, hipEventDisableTiming) != hipSuccess))
+        rc = fail(OFDM_ERR_HIP, "second stream / events of the stream block");
     auto tw = make_twiddles(N);
     // utsa: parity of MM decides the ZC form (:56); gr-RXOFDM: parity of num_synch_bins (synch_and_chan_est.py:56-61)
     auto zc = make_zc(MM, root, c->compat == OFDM_COMPAT_UTSA ? MM : Ks);
@@ -408,7 +428,12 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_zc, size_t(MM) + zcp.size());
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_edf, rows * Kd);
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_pack, rows * Kd);
-    if (rc == OFDM_OK && hipHostMalloc(reinterpret_cast<void**>(&h->pin_tsr), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+    if (rc == OFDM_OK && (hipHostMalloc(reinterpret_cast<void**>(&h->pin_tsr), 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+                          hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), ofdm_rx::PIN_BYTES, hipHostMallocMapped) != hipSuccess ||
+                          hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), ofdm_rx::PIN_BYTES, hipHostMallocMapped) != hipSuccess ||
+                          hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_tsr_dev), h->pin_tsr, 0) != hipSuccess ||
+                          hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_in_dev), h->pin_in, 0) != hipSuccess ||
+                          hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_out_dev), h->pin_out, 0) != hipSuccess))
         rc = fail(OFDM_ERR_NOMEM, "pinned host allocation failed");
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_tsr, 4);
     if (rc == OFDM_OK) rc = dev_alloc(&h->s_H, size_t(2) * N);
@@ -626,7 +651,12 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
         if (rc != OFDM_OK) return rc;
         h->in_cap = cap;
     }
-    if (n_in > 0) HIP_TRY(hipMemcpyAsync(h->d_in, h_in, size_t(n_in) * sizeof(cf), hipMemcpyHostToDevice, s));
+    // The upload is issued where the search is set up (below): the one-synchronisation path sends the head of the buffer first and
+    // runs the first stage of the search under the rest of it.
+    bool uploaded = n_in == 0;
+    auto upload = [&](int64_t from, int64_t to) -> hipError_t {
+        return hipMemcpyAsync(h->d_in + from, h_in + 2 * from, size_t(to - from) * sizeof(cf), hipMemcpyHostToDevice, s);
+    };
 
     const int64_t n_unique = n_in / L;                                       // :140
     const int64_t n_data_symb = int64_t(double(n_unique) * (double(D) / double(SD)));   // :141 int(n * (D/(S+D)))
@@ -666,8 +696,12 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                 for (int r = 3; r < rows_; r += SD) ++n_del_;
                 const bool shape_ok = int64_t(rows_ - n_del_) == n_data_symb && (h->count == 0 || n_data_symb * Kd <= n_out);
                 if (rows_ok && shape_ok && h->seg_armed) {
+                    const size_t out_bytes = size_t(n_data_symb) * Kd * sizeof(cf);
+                    const bool in_place_in = size_t(n_in) * sizeof(cf) <= ofdm_rx::PIN_BYTES;
+                    const bool in_place_out = out_bytes <= ofdm_rx::PIN_BYTES;
+                    const cf* iq_dev = in_place_in ? h->pin_in_dev : h->d_in;
                     SyncArgs fa{};
-                    fa.iq = h->d_in;
+                    fa.iq = iq_dev;
                     fa.frame_stride = n_in;
                     fa.frame_len = n_in;
                     fa.n_frames = 1;
@@ -681,6 +715,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                     fa.n_seg = int((p_valid - p0 + fa.seg_len - 1) / fa.seg_len);
                     fa.seg_state = h->d_seg_state;
                     fa.tsr = h->s_tsr;
+                    fa.tsr_host = h->pin_tsr_dev;
                     fa.H = h->s_H + size_t(row) * N;
                     fa.H_for_gain = (row == 0) ? nullptr : h->s_H;                          // :242 always row 0
                     fa.gain = h->s_gain;
@@ -689,12 +724,37 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                     fa.eqg = h->s_eqg;
                     fa.yscratch = h->s_ysc;
                     h->seg_armed = false;
-                    HIP_TRY(launch_rx_sync(d, fa, s));
-                    HIP_TRY(hipMemcpyAsync(h->pin_tsr, h->s_tsr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+                    // samples the first SYNC_STAGE_SEGS segments can touch: their last trial's windows and screening edges
+                    const int64_t head = p0 + int64_t(SYNC_STAGE_SEGS) * fa.seg_len + int64_t(S) * L + N + d.cp + 64;
+                    if (in_place_in) {
+                        std::memcpy(h->pin_in, h_in, size_t(n_in) * sizeof(cf));
+                        fa.seg_final = 1;
+                        HIP_TRY(launch_rx_sync(d, fa, s));
+                    } else if (fa.n_seg > 2 * SYNC_STAGE_SEGS && head < n_in / 2) {
+                        HIP_TRY(upload(0, head));
+                        HIP_TRY(hipEventRecord(h->ev_up, s));
+                        HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_up, 0));
+                        fa.seg_base = 0;
+                        fa.seg_launch = SYNC_STAGE_SEGS;
+                        fa.seg_final = 0;
+                        HIP_TRY(launch_rx_sync(d, fa, h->stream2));
+                        HIP_TRY(hipEventRecord(h->ev_s1, h->stream2));
+                        HIP_TRY(upload(head, n_in));                     // (pageable source: the host is held here while stage 1 runs)
+                        HIP_TRY(hipStreamWaitEvent(s, h->ev_s1, 0));
+                        fa.seg_base = SYNC_STAGE_SEGS;
+                        fa.seg_launch = fa.n_seg - SYNC_STAGE_SEGS;
+                        fa.seg_final = 1;
+                        HIP_TRY(launch_rx_sync(d, fa, s));
+                    } else {
+                        HIP_TRY(upload(0, n_in));
+                        fa.seg_final = 1;
+                        HIP_TRY(launch_rx_sync(d, fa, s));
+                    }
+                    uploaded = true;
                     const int64_t n_dsym_all = n_pat_all * D;                               // the device applies the guard per pattern
                     if (n_dsym_all > 0) {
                         DemodArgs da{};
-                        da.iq = h->d_in;
+                        da.iq = iq_dev;
                         da.frame_stride = n_in;
                         da.frame_len = n_in;
                         da.n_frames = 1;
@@ -710,10 +770,11 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                         HIP_TRY(launch_rx_demod(d, da, s));
                     }
                     if (h->count > 0) {                                                     // :257
-                        HIP_TRY(launch_pack_rows(h->d_edf, rows_, Kd, SD, h->d_pack, s));
-                        HIP_TRY(hipMemcpyAsync(h_out, h->d_pack, size_t(n_data_symb) * Kd * sizeof(cf), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(launch_pack_rows(h->d_edf, rows_, Kd, SD, in_place_out ? h->pin_out_dev : h->d_pack, s));
+                        if (!in_place_out) HIP_TRY(hipMemcpyAsync(h_out, h->d_pack, out_bytes, hipMemcpyDeviceToHost, s));
                     }
                     HIP_TRY(hipStreamSynchronize(s));                                       // the one wait of this call
+                    if (h->count > 0 && in_place_out) std::memcpy(h_out, h->pin_out, out_bytes);
                     h->seg_armed = true;
                     const int* t4 = h->pin_tsr;
                     if (t4[3]) {
@@ -743,6 +804,8 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                     return n_out;                                                            // :262
                 }
             }
+            HIP_TRY(upload(0, n_in));
+            uploaded = true;
             SyncArgs fa{};
             fa.iq = h->d_in;
             fa.frame_stride = n_in;
@@ -771,6 +834,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                 HIP_TRY(hipMemcpy(h->d_seg_state, seg0, sizeof seg0, hipMemcpyHostToDevice));
             }
             h->seg_armed = false;
+            fa.seg_final = 1;
             HIP_TRY(launch_rx_sync(d, fa, s));
             int t4[4];
             HIP_TRY(hipMemcpyAsync(t4, h->s_tsr, sizeof(t4), hipMemcpyDeviceToHost, s));
@@ -787,6 +851,10 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                 trials_run = int(p_valid - p0);
             }
             p0 = p_valid;
+        }
+        if (!uploaded) {
+            HIP_TRY(upload(0, n_in));
+            uploaded = true;
         }
         int win = 128;
         std::vector<float> tm(ofdm_rx::TRIAL_CAP);

@@ -64,10 +64,20 @@ struct SyncArgs {
     unsigned* stamps;        // OFDM_EXPERIMENTS build only: [workgroups][8] cycle sums per phase of the scan kernel, or null
     int keep_on_miss;        // mode 0: a frame without an accepted trial leaves every output row untouched (stream block: the old
                              // estimate stays in force, SynchAndChanEst.py:166-219 only writes on detection) except tsr[3] = 0
+    int* tsr_host;           // mode 0: optional second copy of the frame's tsr words in device-visible HOST memory (stream block: the
+                             // host reads them after its one synchronisation without a copy in the stream), or null
     int n_seg;               // screened search of ONE long buffer (n_frames == 1): > 0 = the trials p_begin .. are cut into n_seg
     int seg_len;             //   segments of seg_len trials searched in parallel; the first accepted trial overall is finalized
-    int* seg_state;          //   [2] device words {first hit so far = INT_MAX, segments done = 0}; the kernel re-arms them
+    int* seg_state;          //   [2] device words {first hit so far = INT_MAX, unused}; the finalize launch re-arms the first
+    int seg_base;            //   this launch covers the segments seg_base .. seg_base + seg_launch - 1 (seg_launch == 0: launch_rx_sync
+    int seg_launch;          //   stages the search itself: the first SYNC_STAGE_SEGS segments, then the rest behind them)
+    int seg_final;           //   1: the launcher adds the one-workgroup launch that finalizes the first hit and re-arms seg_state[0]
+                             //   (0 only for the earlier parts of a search the caller stages itself)
 };
+
+// Segments of the first stage of a staged segment search: a continuing stream finds its sync a few symbols into the buffer, so
+// the later segments, launched behind the first stage, see the published hit and leave at once.
+constexpr int SYNC_STAGE_SEGS = 64;
 
 struct DemapArgs {
     const cf* sym;

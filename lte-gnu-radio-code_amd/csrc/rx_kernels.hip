@@ -179,6 +179,15 @@ __device__ __forceinline__ void sync_finalize(const RxDev& rx, const SyncArgs& a
             o[2] = found ? int(ms) : 0;                                                  // :175
         }
         o[3] = found ? 1 : 0;
+        if (a.tsr_host) {
+            int* oh = a.tsr_host + int64_t(frame) * 4;
+            if (found || !a.keep_on_miss) {
+                oh[0] = o[0];
+                oh[1] = o[1];
+                oh[2] = o[2];
+            }
+            oh[3] = found ? 1 : 0;
+        }
     }
     active = active && (found || !a.keep_on_miss);     // from here on `active` only gates the stores
     // Z (register slot order) -> LDS in natural bin order, then a rolled loop over this lane's bins: the finalize
@@ -459,9 +468,11 @@ __device__ __forceinline__ void cfma(cf& u, cf d, cf g) {
 
 //
 // SEG (stream block, one long buffer): the trial range is cut into segments of a.seg_len trials, one per workgroup slot, searched in
-// parallel.  Each segment publishes its first accepted trial with an atomicMin; the segment that finishes last re-evaluates the
-// overall minimum exactly (the same code at the same trial: the same numbers) and finalizes it, so the launch still returns
-// the reference's "first accepted trial" and its estimate.  Segments behind an already published hit stop early.
+// parallel, in one or more launches.  Each segment publishes its first accepted trial with an atomicMin; a one-workgroup launch
+// behind them (a.seg_final) re-evaluates the overall minimum exactly (the same code at the same trial: the same numbers) and
+// finalizes it, so the search still returns the reference's "first accepted trial" and its estimate.  Segments behind an
+// already published hit stop early.  (Round 2 let the segment that finished last finalize: one ticket per segment on one word,
+// ~2000 serialised atomics per 240-symbol buffer -- most of that launch's 0.12 ms.)
 template <int N, int MINW = 2, bool SEG = false>
 __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev rx, SyncArgs a) {
     using PL = Plan<N>;
@@ -475,6 +486,24 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     cf* lds = smem + slot * WgLds<N>::STRIDE;
     float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
     int* redi = reinterpret_cast<int*>(red);
+    if constexpr (SEG) {
+        if (a.seg_final && a.keep_on_miss &&
+            __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0x7fffffff) {
+            // finalize launch of a search without a hit (the word is stable: every search launch lies before this one in the
+            // stream): the old estimate stays in force, only "not detected" is reported -- no table, no transform
+            if (tid == 0) {
+                a.tsr[3] = 0;
+                if (a.tsr_host) a.tsr_host[3] = 0;
+            }
+            return;
+        }
+        if (!a.seg_final) {
+            // A workgroup whose segments all lie behind an already published hit has nothing to do -- before any table is loaded.
+            // (Voted: the waves of a workgroup may read different values of the word, which only ever decreases.)
+            const int64_t first_p = int64_t(a.p_begin) + (int64_t(a.seg_base) + int64_t(blockIdx.x) * SLOTS) * a.seg_len;
+            if (__syncthreads_and(__hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < first_p ? 1 : 0)) return;
+        }
+    }
     const cf* w1tab = wg_init_w1<N>(smem, rx.tw, tid);
     cf* extra = smem + WgLds<N>::STRIDE * SLOTS + WgLds<N>::W1_ELEMS + slot * SG::EXTRA;
     cf* xo = extra + SG::DL_OFF;          // window-edge samples leaving; overwritten by dl[i] = xn[i] - xo[i]
@@ -489,8 +518,9 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     std::conditional_t<PL::R0 == 16, CompactTwiddles<N>, LaneTwiddles<N>> tw;
     load_twiddles(tw, rx.tw, t);
 
-    const int64_t unit = int64_t(blockIdx.x) * SLOTS + slot;
-    bool active = unit < (SEG ? a.n_seg : a.n_frames);
+    const int64_t unit = (SEG ? int64_t(a.seg_base) : 0) + int64_t(blockIdx.x) * SLOTS + slot;
+    // (a staged segment search: this launch owns the segments seg_base .. seg_base + seg_launch - 1 of n_seg)
+    bool active = unit < (SEG ? int64_t(min(a.n_seg, a.seg_base + a.seg_launch)) : a.n_frames);
     const int frame = (active && !SEG) ? int(unit) : 0;
     const cf* frame_iq = a.iq + int64_t(frame) * a.frame_stride;
     // (a run-time pointer on purpose: with a literal nullptr hipcc's schedule of the trial needs ~3000 spills at 168 VGPRs)
@@ -506,6 +536,18 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         const int64_t first = int64_t(a.p_begin) + (active ? unit : 0) * a.seg_len;
         P0 = int(first < (1 << 30) ? first : (1 << 30));
         if (int64_t(nvalid) > first + a.seg_len) nvalid = int(first + a.seg_len);
+    }
+
+    if constexpr (SEG) {
+        if (a.seg_final) {
+            // the launch behind the search: ONE slot re-evaluates the published first hit exactly (the same code at the same
+            // trial: the same numbers), finalizes it and re-arms the word for the next search
+            int win = 0x7fffffff;
+            if (unit == 0) win = __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            active = unit == 0;
+            P0 = (active && win != 0x7fffffff) ? win : 0;
+            nvalid = (active && win != 0x7fffffff) ? win + 1 : 0;
+        }
     }
 
     // the table G[1 .. B + cp] -> LDS once; entries -BMAX .. 0 are ZERO: alignments behind the current trial add nothing, branch-free
@@ -545,7 +587,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
 #else
 #define SCAN_STAMP(i) do { } while (0)
 #endif
-    for (int pass = 0;; ++pass) {
+    {
     for (;;) {
         bool blk_on = !found && P0 < nvalid;
         if constexpr (SEG) {
@@ -554,7 +596,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             // values, so they vote: ANY wave that saw the earlier hit stops the segment (the word only ever decreases) and blk_on
             // is workgroup-uniform as the anchor trial below assumes.  Where a workgroup holds several segments (SLOTS > 1) a
             // segment lies inside one wave, whose lanes read the word in one instruction: uniform per segment without a vote.
-            const bool stop = pass == 0 && __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P0;
+            const bool stop = !a.seg_final && __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P0;
             if constexpr (SLOTS == 1) {
                 if (__syncthreads_or(stop ? 1 : 0)) blk_on = false;
             } else if (stop) {
@@ -894,34 +936,14 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         if (nb > 0) P0 += (cand < nb) ? cand : nb;
         SCAN_STAMP(5);                                                       // .. candidate reduction
     }
-    if (!SEG || pass == 1) break;
-    if constexpr (SEG) {
-        // publish, take a ticket; the slot holding the last ticket goes round once more with the winning trial as its only one
-        wg_barrier();
-        if (t == 0) {
-            int last = 0;
-            if (active) {
-                if (found) atomicMin(a.seg_state, Phit);
-                __threadfence();
-                last = atomicAdd(a.seg_state + 1, 1) == a.n_seg - 1;
-            }
-            int win = 0x7fffffff;
-            if (last) {
-                __threadfence();
-                win = atomicExch(a.seg_state, 0x7fffffff);               // read the minimum and re-arm both words for the next launch
-                atomicExch(a.seg_state + 1, 0);
-            }
-            cflag[0] = last ? win : -1;                                  // -1: this slot is not the last one
-        }
-        wg_barrier();
-        const int win = cflag[0];
-        wg_barrier();
-        if (!__syncthreads_or(win >= 0 ? 1 : 0)) return;                // no slot of this workgroup holds the last ticket
-        active = win >= 0;
-        found = false;
-        P0 = (active && win != 0x7fffffff) ? win : 0;
-        nvalid = (active && win != 0x7fffffff) ? win + 1 : 0;
     }
+    if constexpr (SEG) {
+        if (!a.seg_final) {
+            // publish and leave: the finalize launch behind the search picks the overall minimum up
+            if (t == 0 && active && found) atomicMin(a.seg_state, Phit);
+            return;
+        }
+        if (tid == 0) __hip_atomic_store(a.seg_state, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     SCAN_STAMP(6);
     sync_finalize<N>(rx, a, frame, active, found, Phit, Zs, zdups, pests, ms, dhats, lds, tw, w1tab, t, ysc);
@@ -1344,8 +1366,30 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
         // sizes keep a second copy of Z and get 256
         if (a.n_seg > 0) {
             if (a.n_frames != 1 || a.seg_len <= 0 || !a.seg_state) return hipErrorInvalidValue;
-            const unsigned gseg = unsigned((int64_t(a.n_seg) + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
-            hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(gseg), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
+            // Staged: every workgroup resident when the launch starts runs its anchor before the first hit can be published, so
+            // one launch over a 240-symbol buffer (~2000 segments) cost ~0.12 ms for a sync that sits in segment ~25.  The first
+            // SYNC_STAGE_SEGS segments go first; the rest are launched behind them and, when the hit is already published,
+            // only take their tickets.  Same decisions: the tickets and the published minimum span both launches.
+            if (a.seg_base < 0 || a.seg_launch < 0 || a.seg_base % Plan<N>::SLOTS) return hipErrorInvalidValue;
+            SyncArgs st = a;
+            int base = a.seg_base;
+            const int end = a.seg_launch > 0 ? std::min(a.n_seg, a.seg_base + a.seg_launch) : a.n_seg;
+            while (base < end) {
+                int cnt = end - base;
+                if (a.seg_launch == 0 && base == 0 && cnt > 2 * SYNC_STAGE_SEGS) cnt = SYNC_STAGE_SEGS;
+                st.seg_base = base;
+                st.seg_launch = cnt;
+                st.seg_final = 0;
+                const unsigned gseg = unsigned((int64_t(cnt) + Plan<N>::SLOTS - 1) / Plan<N>::SLOTS);
+                hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(gseg), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, st);
+                base += cnt;
+            }
+            if (a.seg_final) {                       // the caller staged the search itself and this was its last part (or all of it)
+                st.seg_base = 0;
+                st.seg_launch = Plan<N>::SLOTS;
+                st.seg_final = 1;
+                hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(1), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, st);
+            }
             return hipGetLastError();
         }
         hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);

@@ -138,13 +138,17 @@ def test_screen_is_off_where_its_preconditions_fail(om):
     assert om.RxEngine(8, 64, 60, 62, (1, 3), 60, 100).set_sync_search(False) is False          # cp too long for one block
 
 
-@pytest.mark.parametrize("N,cp,Kd,n_sym", [(64, 16, 60, 12), (256, 18, 152, 12), (2048, 144, 1200, 12)])
+@pytest.mark.parametrize("N,cp,Kd,n_sym", [(64, 16, 60, 12), (256, 18, 152, 12), (2048, 144, 1200, 12),
+                                            # long buffers: the search is staged (first 64 segments on a second stream under the
+                                            # rest of the upload, the others behind them), short ones go through pinned memory
+                                            (256, 18, 152, 400), (2048, 144, 1200, 60)])
 def test_stream_block_uses_the_screened_search_with_the_same_outcome(om, N, cp, Kd, n_sym):
-    """`work()` on host buffers (the GNU Radio path) searches, accepts and finalizes in one launch.  A sequence of calls -- sync
-    deep in the buffer, at sample 0, a buffer of noise only (nothing found: the previous estimate must stay), then a late sync
-    again -- must leave the same report, output items and state rows as the exhaustive search and as the oracle."""
+    """`work()` on host buffers (the GNU Radio path) searches, accepts and finalizes without a host decision in between.  A
+    sequence of calls -- sync deep in the buffer, at sample 0, a buffer of noise only (nothing found: the previous estimate must
+    stay), then a late sync again (in a long buffer: far behind the segments of the search's first stage) -- must leave the same
+    report, output items and state rows as the exhaustive search and as the oracle."""
     L = N + cp
-    leads = [L + 7, 0, None, 3 * L - 1, 17]
+    leads = [L + 7, 0, None, (3 if n_sym < 100 else n_sym // 3) * L - 1, 17]
     rng = np.random.default_rng(N + 1)
     bufs = []
     for ld in leads:
