@@ -736,7 +736,7 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_up, 0));
                         fa.seg_base = 0;
                         fa.seg_launch = SYNC_STAGE_SEGS;
-                        fa.seg_final = 0;
+                        fa.seg_final = 2;                                // a hit in the first stage is finalized under the upload too
                         HIP_TRY(launch_rx_sync(d, fa, h->stream2));
                         HIP_TRY(hipEventRecord(h->ev_s1, h->stream2));
                         HIP_TRY(upload(head, n_in));                     // (pageable source: the host is held here while stage 1 runs)

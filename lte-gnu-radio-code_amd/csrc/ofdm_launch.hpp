@@ -68,11 +68,13 @@ struct SyncArgs {
                              // host reads them after its one synchronisation without a copy in the stream), or null
     int n_seg;               // screened search of ONE long buffer (n_frames == 1): > 0 = the trials p_begin .. are cut into n_seg
     int seg_len;             //   segments of seg_len trials searched in parallel; the first accepted trial overall is finalized
-    int* seg_state;          //   [2] device words {first hit so far = INT_MAX, unused}; the finalize launch re-arms the first
+    int* seg_state;          //   [2] device words {first hit so far = INT_MAX, finalized early = 0}; the last finalize launch re-arms them
     int seg_base;            //   this launch covers the segments seg_base .. seg_base + seg_launch - 1 (seg_launch == 0: launch_rx_sync
     int seg_launch;          //   stages the search itself: the first SYNC_STAGE_SEGS segments, then the rest behind them)
-    int seg_final;           //   1: the launcher adds the one-workgroup launch that finalizes the first hit and re-arms seg_state[0]
-                             //   (0 only for the earlier parts of a search the caller stages itself)
+    int seg_final;           //   the one-workgroup launch the launcher adds behind the search launches: 1 = the search ends here
+                             //   (finalize the first hit unless an early finalize did, report a miss, re-arm seg_state); 2 = early
+                             //   finalize behind a first stage the caller runs on its own (a hit there is the first hit: finalize it
+                             //   and mark seg_state[1]; nothing found: leave everything to the later stages); 0 = none
 };
 
 // Segments of the first stage of a staged segment search: a continuing stream finds its sync a few symbols into the buffer, so

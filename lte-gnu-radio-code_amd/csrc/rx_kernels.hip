@@ -487,15 +487,25 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
     float* red = reinterpret_cast<float*>(lds + WgLds<N>::ELEMS);
     int* redi = reinterpret_cast<int*>(red);
     if constexpr (SEG) {
-        if (a.seg_final && a.keep_on_miss &&
-            __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0x7fffffff) {
-            // finalize launch of a search without a hit (the word is stable: every search launch lies before this one in the
-            // stream): the old estimate stays in force, only "not detected" is reported -- no table, no transform
-            if (tid == 0) {
-                a.tsr[3] = 0;
-                if (a.tsr_host) a.tsr_host[3] = 0;
+        if (a.seg_final) {
+            // (both words are stable here: every search launch whose result this launch looks at lies before it in its stream)
+            const int w0 = __hip_atomic_load(a.seg_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int done = __hip_atomic_load(a.seg_state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.seg_final == 2) {
+                if (w0 == 0x7fffffff) return;                  // early finalize, nothing found yet: the later stages go on
+            } else if (done || (w0 == 0x7fffffff && a.keep_on_miss)) {
+                // the early finalize has done the work, or the search ends without a hit (the old estimate stays in force, only
+                // "not detected" is reported): re-arm, no table, no transform
+                if (tid == 0) {
+                    if (!done) {
+                        a.tsr[3] = 0;
+                        if (a.tsr_host) a.tsr_host[3] = 0;
+                    }
+                    __hip_atomic_store(a.seg_state, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.seg_state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
             }
-            return;
         }
         if (!a.seg_final) {
             // A workgroup whose segments all lie behind an already published hit has nothing to do -- before any table is loaded.
@@ -943,7 +953,14 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             if (t == 0 && active && found) atomicMin(a.seg_state, Phit);
             return;
         }
-        if (tid == 0) __hip_atomic_store(a.seg_state, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        if (tid == 0) {
+            if (a.seg_final == 2) {
+                __hip_atomic_store(a.seg_state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // finalized; word 0 stays:
+            } else {                                                                                   // it stops the later stages
+                __hip_atomic_store(a.seg_state, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+                __hip_atomic_store(a.seg_state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     SCAN_STAMP(6);
     sync_finalize<N>(rx, a, frame, active, found, Phit, Zs, zdups, pests, ms, dhats, lds, tw, w1tab, t, ysc);
@@ -1384,10 +1401,10 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
                 hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(gseg), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, st);
                 base += cnt;
             }
-            if (a.seg_final) {                       // the caller staged the search itself and this was its last part (or all of it)
+            if (a.seg_final) {                       // 1: the search ends with this part; 2: early finalize behind a first stage
                 st.seg_base = 0;
                 st.seg_launch = Plan<N>::SLOTS;
-                st.seg_final = 1;
+                st.seg_final = a.seg_final;
                 hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(1), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, st);
             }
             return hipGetLastError();
