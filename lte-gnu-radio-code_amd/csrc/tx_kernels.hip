@@ -97,9 +97,11 @@ __device__ __forceinline__ void tx_fetch_issue(const uint8_t* bits, unsigned bas
     } else if constexpr (KIND == 14) {
 #pragma unroll
         for (int q = 0; q < P; ++q) {
+            // two byte loads, the second only where the symbol reaches into the next byte (one unaligned two-byte load per bin was
+            // measured 3-7 % slower: profiles/r03_tx_ab.txt)
             const unsigned b0 = (base + max(li[q], 0)) * 6u;
             f.w[0][q] = bits[b0 >> 3];
-            f.w[1][q] = bits[(b0 >> 3) + ((b0 & 7u) > 2u ? 1u : 0u)];      // the second byte only where the symbol reaches into it
+            f.w[1][q] = bits[(b0 >> 3) + ((b0 & 7u) > 2u ? 1u : 0u)];
         }
     }
     // one empty asm with every result as an operand: the loads above are all issued before the first of them is used
@@ -182,7 +184,8 @@ __device__ __forceinline__ void tx_time_from_fft(cf (&v)[Plan<N>::P]) {
 // and the conjugation a sign: both are exact, so they are folded into the reductions' results and into the final scale -- the
 // staged samples stay raw and tx_cp_store applies (scale/N, -scale/N).  Every float the staged pipeline (IFFT stage: conj and
 // 1/N explicitly, then this function with RAW = false) produces is reproduced bit for bit.
-template <int N, bool RAW = false>
+// STAGE = false: nothing is staged in LDS (the caller stores from its registers, tx_cp_store_direct); only the reductions remain.
+template <int N, bool RAW = false, bool STAGE = true>
 __device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)[Plan<N>::P], cf* lds, float* red, int t) {
     using PL = Plan<N>;
     constexpr int T = PL::T;
@@ -194,7 +197,7 @@ __device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)
         for (int kl = 0; kl < PL::RL; ++kl) {
             const int m = (t + T * j) + PL::NC * kl;
             const cf xv = x[out_slot<N>(j, kl)];
-            lds[m] = xv;
+            if constexpr (STAGE) lds[m] = xv;
             // a register slot holds the T consecutive samples [base, base + T): the CP weight is decided per slot on the scalar
             // unit wherever the slot lies wholly on one side of the CP boundary (x2 and x1 are exact: same sums either way)
             const int base = T * j + PL::NC * kl;
@@ -222,7 +225,7 @@ __device__ __forceinline__ float tx_cp_norm_stage(const TxDev& tx, const cf (&x)
             r3[2] = sy;
         }
     }
-    wg_barrier();
+    if constexpr (STAGE || T > 64) wg_barrier();
     if constexpr (T > 64) {
         e = sx = sy = 0.f;
 #pragma unroll
@@ -289,15 +292,49 @@ __device__ __forceinline__ void tx_cp_store(const TxDev& tx, const cf* lds, floa
     }
 }
 
+// The same samples straight from the registers the transform left them in (one symbol per workgroup, T >= 64): register slot
+// (j, kl) of the T lanes is T consecutive time samples, so a wave's store instruction covers 512 contiguous bytes; the cyclic prefix
+// is a second store from the one or two slots that reach into the last cp samples.  No staging copy in LDS (N writes + L reads per
+// symbol) and neither of the two barriers that fenced it.  The products are those of tx_cp_store: the same floats.
+template <int N>
+__device__ __forceinline__ void tx_cp_store_direct(const TxDev& tx, const cf (&x)[Plan<N>::P], float scale, int t, cf* o, bool active) {
+    using PL = Plan<N>;
+    constexpr int T = PL::T;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    if (!active) return;
+    const int cp0 = N - tx.cp;
+    cf* body = o + tx.cp + t;
+    cf* pre = o + t - cp0;
+#pragma unroll
+    for (int j = 0; j < PL::C; ++j) {
+#pragma unroll
+        for (int kl = 0; kl < PL::RL; ++kl) {
+            const int base = T * j + PL::NC * kl;
+            const cf xv = x[out_slot<N>(j, kl)];
+            const f2 q{xv.x * scale, xv.y * -scale};
+            __builtin_nontemporal_store(q, reinterpret_cast<f2*>(body + base));
+            if (base + T - 1 >= cp0) {                                    // (scalar: most slots lie wholly before the prefix)
+                if (base + t >= cp0) __builtin_nontemporal_store(q, reinterpret_cast<f2*>(pre + base));
+            }
+        }
+    }
+}
+
+#ifndef OFDM_TX_DIRECT
+#define OFDM_TX_DIRECT 1        // 0: the fused kernel stages every symbol in LDS like the stage kernels do (A/B in DESIGN.md 4.3)
+#endif
+
 // One workgroup slot walks symbols unit, unit + stride, ...: twiddles and the pass-1 table are set up once per workgroup.
 // (Requesting the next symbol's bit words ahead of this symbol's stores -- the software pipeline of the receive kernel -- was
 // measured and bought nothing here: the kernel is VALU-issue-bound at 4 waves per SIMD, not waiting for memory.)
 #ifndef OFDM_TX_MINW
-#define OFDM_TX_MINW 3          // waves per SIMD the fused transmit kernel is compiled for (4: a 128-VGPR budget; A/B in DESIGN.md 4.3)
+#define OFDM_TX_MINW 4          // waves per SIMD the fused transmit kernel is compiled for from 1024-pt up (a 128-VGPR budget: 0-2
+                                // spilled values once the symbol leaves from registers; A/B in DESIGN.md 4.3).  Smaller sizes and
+                                // packed 64-QAM (two byte loads per bin in flight: 13-16 spills at 128) keep 3
 #endif
 constexpr int TX_LUT_ELEMS = 72;         // 64 points + the zero entry, rounded up
 template <int N, int KIND>
-__global__ void __launch_bounds__(Plan<N>::WG, OFDM_TX_MINW) tx_modulate_kernel(TxDev tx, ModArgs a) {
+__global__ void __launch_bounds__(Plan<N>::WG, (Plan<N>::SLOTS == 1 && KIND != 14) ? OFDM_TX_MINW : 3) tx_modulate_kernel(TxDev tx, ModArgs a) {
     using PL = Plan<N>;
     constexpr int T = PL::T, P = PL::P;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -414,11 +451,17 @@ __global__ void __launch_bounds__(Plan<N>::WG, OFDM_TX_MINW) tx_modulate_kernel(
             for (int n0 = 0; n0 < P; ++n0) v[n0] = cf{0.f, 0.f};
         }
         wg_fft<N>(v, lds, tw, w1tab, t);                                         // :199
-        wg_barrier();
         // conj and 1/N of ifft(X) = conj(fft(conj(X))) / N are exact: folded into the reductions and the final scale
-        const float scale = tx_cp_norm_stage<N, true>(tx, v, lds, red, t);
-        tx_cp_store<N, true>(tx, lds, scale, t, a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L, active);
-        wg_barrier();                                                            // the staged symbol has been read by every lane
+        cf* o = a.iq + int64_t(frame) * a.frame_stride + int64_t(sym) * tx.L;
+        if constexpr (PL::SLOTS == 1 && OFDM_TX_DIRECT) {
+            const float scale = tx_cp_norm_stage<N, true, false>(tx, v, lds, red, t);
+            tx_cp_store_direct<N>(tx, v, scale, t, o, active);
+        } else {
+            wg_barrier();
+            const float scale = tx_cp_norm_stage<N, true>(tx, v, lds, red, t);
+            tx_cp_store<N, true>(tx, lds, scale, t, o, active);
+            wg_barrier();                                                        // the staged symbol has been read by every lane
+        }
     }
 }
 
