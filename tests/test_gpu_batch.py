@@ -526,3 +526,44 @@ def test_lds_request_grows_with_the_bin_count_inside_one_process(om):
         o.work(iq[0], np.zeros(fl, np.complex64))
         assert_close(eq, o.est_data_freq[[r for r in range(n_sym) if r % 4 != 3]], "Kd %d" % Kd)
         assert np.array_equal(np.unpackbits(d_bp.download(np.uint8, nds * Kd * 4 // 8)), orc.demap_hard(eq.ravel(), mod))
+
+
+@pytest.mark.parametrize("N,cp,Kd,mod,n_frames", [(64, 16, 60, "QPSK", 6000), (128, 9, 72, "16QAM", 3000), (256, 18, 180, "16QAM", 1500),
+                                                  (512, 36, 300, "64QAM", 1200)])
+def test_small_sizes_many_frames_loopback_and_sampled_oracle(om, N, cp, Kd, mod, n_frames):
+    """Below 1024-pt a chunk of the demod launch is a whole frame or a large part of one once the batch is big (few-frame
+    batches, which every other small-size test uses, are cut finer): bits -> HIP TX -> HIP channel -> HIP RX is the identity on
+    EVERY frame of a large batch (packed bits, device-side error count), and sampled frames equal the oracle's rows."""
+    import torch
+    n_sym, L = 240, N + cp
+    bps = orc.BITS_PER_SYMBOL[mod]
+    txe = om.TxEngine(N, cp, N - 2, Kd, (1, 3), mod)
+    rxe = om.RxEngine(n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7, modulation=mod)
+    nb = txe.bits_per_frame(n_sym)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(N)
+    bits = torch.randint(0, 256, (n_frames, nb // 8), dtype=torch.uint8, device=dev, generator=gen)
+    fl = n_sym * L
+    iq = torch.empty((n_frames, fl, 2), dtype=torch.float32, device=dev)
+    rxb = torch.empty_like(iq)
+    taps = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    taps[0, 0] = 1
+    txe.modulate_frames(bits.data_ptr(), n_frames, n_sym, iq.data_ptr(), bits_mode=om.BITS_PACKED)
+    txe.channel(iq.data_ptr(), n_frames, fl, fl, taps.data_ptr(), 1, rxb.data_ptr(), fl, fl, noise_var=1e-6, seed=3)
+    nds = rxe.data_symbols_per_frame(fl)
+    assert nds * Kd * bps == nb
+    out = torch.full((n_frames, nb // 8), 0xA5, dtype=torch.uint8, device=dev)
+    eq = torch.full((n_frames, nds * Kd, 2), float("nan"), dtype=torch.float32, device=dev)
+    assert rxe.demod_frames(rxb.data_ptr(), n_frames, fl, fl, eq.data_ptr(), out.data_ptr(), om.BITS_PACKED, None) == nds
+    torch.cuda.synchronize()
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    om.count_bit_errors(out.data_ptr(), bits.data_ptr(), out.numel(), cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0
+    rows = [r for r in range(n_sym) if r % 4 != 3]        # est_data_freq rows the patterns write (row p*(S+D) + n)
+    for f in (0, n_frames // 2 + 1, n_frames - 1):
+        x = torch.view_as_complex(rxb[f]).cpu().numpy()
+        o = orc.RxOracle(n_sym, N, cp, N - 2, [1, 3], Kd, 100, 0.7, force_fp64=True)
+        o.work(x, np.zeros(fl, np.complex64))
+        got = torch.view_as_complex(eq[f]).cpu().numpy().reshape(nds, Kd)
+        assert_close(got, o.est_data_freq[rows], "frame %d" % f)
