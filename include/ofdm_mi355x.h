@@ -311,6 +311,13 @@ int ofdm_count_bit_errors(int32_t device, const uint8_t* d_a, const uint8_t* d_b
  * sym_out_bytes).  Asynchronous on `stream`. */
 int ofdm_bandwidth_probe(int32_t device, const void* d_in, void* d_out, int64_t bytes, int32_t mode, int32_t sym_in_bytes,
                          int32_t gap_bytes, int32_t sym_out_bytes, int64_t n_sym, void* stream);
+/* Frame partition of the N-GPU path: frames are independent (each is one reference work() buffer: own sync, own estimate,
+ * SynchAndChanEst.py:135-262 keeps no state between the buffers the batch entry takes), so rank `rank` of `world` owns the
+ * contiguous frames [*first, *first + *count) and calls ofdm_rx_demod_frames on them with its own handle on its own device; the
+ * only exchange is the caller's all-gather of the packed bits.  The same rule as ofdm_mi355x.dist.shard_frames and bench.py, for
+ * hosts that are not Python.  n_frames_total must be a multiple of world (an all-gather needs equal counts: pad the batch), else
+ * OFDM_ERR_INVALID.  Host arithmetic only: no device is touched. */
+int ofdm_shard_frames(int64_t n_frames_total, int32_t world, int32_t rank, int64_t* first, int64_t* count);
 int ofdm_abi_version(void);
 const char* ofdm_last_error(void);
 /* plain device memory helpers so hosts without torch can drive the batch path */

@@ -273,6 +273,16 @@ struct ofdm_tx {
 extern "C" {
 
 int ofdm_abi_version(void) { return OFDM_ABI_VERSION; }
+
+int ofdm_shard_frames(int64_t n_frames_total, int32_t world, int32_t rank, int64_t* first, int64_t* count) {
+    if (!first || !count || world < 1 || rank < 0 || rank >= world || n_frames_total < 0)
+        return fail(OFDM_ERR_INVALID, "ofdm_shard_frames: bad argument");
+    if (n_frames_total % world)
+        return fail(OFDM_ERR_INVALID, "n_frames_total=%lld is not a multiple of world=%d", (long long)n_frames_total, int(world));
+    *count = n_frames_total / world;
+    *first = int64_t(rank) * *count;
+    return OFDM_OK;
+}
 const char* ofdm_last_error(void) { return g_last_error.c_str(); }
 
 int ofdm_device_malloc(int32_t device, void** d_ptr, int64_t bytes) {

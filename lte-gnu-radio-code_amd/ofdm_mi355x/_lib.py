@@ -74,6 +74,7 @@ FO_MAX_SYNC = 100
 # name -> (restype, argtypes): exactly the prototypes of include/ofdm_mi355x.h
 PROTOTYPES = {
     "ofdm_abi_version": (C.c_int, []),
+    "ofdm_shard_frames": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ofdm_last_error": (C.c_char_p, []),
     "ofdm_device_malloc": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int64]),
     "ofdm_device_free": (C.c_int, [C.c_int32, C.c_void_p]),

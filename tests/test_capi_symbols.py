@@ -28,6 +28,26 @@ def test_library_exports_the_whole_header():
     assert lib.ofdm_abi_version() == 1
 
 
+def test_c_frame_partition_equals_the_python_rule():
+    """ofdm_shard_frames (hosts that are not Python) against ofdm_mi355x.dist.shard_frames: host arithmetic, no device."""
+    import ctypes as C
+    import ofdm_mi355x
+    from ofdm_mi355x import _lib, dist
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    lib = ofdm_mi355x.load()
+    first, count = C.c_int64(-1), C.c_int64(-1)
+    for total, world in ((4369 * 8, 8), (12, 4), (7, 1), (0, 3), (34952, 2)):
+        for rank in range(world):
+            assert lib.ofdm_shard_frames(total, world, rank, C.byref(first), C.byref(count)) == 0
+            assert (first.value, count.value) == dist.shard_frames(total, world, rank)
+    assert lib.ofdm_shard_frames(10, 4, 0, C.byref(first), C.byref(count)) != 0          # ValueError in Python
+    with pytest.raises(ValueError):
+        dist.shard_frames(10, 4, 0)
+    assert lib.ofdm_shard_frames(8, 4, 4, C.byref(first), C.byref(count)) != 0
+    assert lib.ofdm_shard_frames(8, 4, 0, None, C.byref(count)) != 0
+
+
 def test_no_silent_cpu_fallback():
     import torch
     import ofdm_mi355x
