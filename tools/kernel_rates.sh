@@ -8,7 +8,15 @@ python3 tools/tx_rate.py 2048 144 1200 16QAM 512 > $OUT/tx_rate.txt 2>&1
 python3 tools/tx_rate.py 2048 144 1200 64QAM 512 >> $OUT/tx_rate.txt 2>&1
 python3 tools/tx_rate.py 1024 72 600 16QAM 1024 >> $OUT/tx_rate.txt 2>&1
 python3 tools/tx_rate.py 4096 288 2400 16QAM 256 >> $OUT/tx_rate.txt 2>&1
+# the same at the bench's own batch sizes (the 512-frame launches above are the round-2 protocol, kept for comparison)
+python3 tools/tx_rate.py 2048 144 1200 16QAM 4369 >> $OUT/tx_rate.txt 2>&1
+python3 tools/tx_rate.py 2048 144 1200 64QAM 4369 >> $OUT/tx_rate.txt 2>&1
+python3 tools/tx_rate.py 2048 144 1200 QPSK 4369 >> $OUT/tx_rate.txt 2>&1
+python3 tools/tx_rate.py 1024 72 600 16QAM 8738 >> $OUT/tx_rate.txt 2>&1
+python3 tools/tx_rate.py 4096 288 2400 16QAM 2184 >> $OUT/tx_rate.txt 2>&1
 python3 tools/demap_rate.py > $OUT/demap_rate.txt 2>&1
+python3 tools/stream_rate.py > $OUT/stream_rate.txt 2>&1
+python3 tools/host_copy_probe.py >> $OUT/stream_rate.txt 2>&1
 if [ "${RATES_ONLY:-0}" = "1" ]; then exit 0; fi
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_tx -- python3 $R/tools/tx_rate.py 2048 144 1200 16QAM 512 > $OUT/kt_tx.txt 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_demap -- python3 $R/tools/demap_rate.py > $OUT/kt_demap.txt 2>&1)
