@@ -101,7 +101,11 @@ def test_batch_frames_without_sync_and_short_frames(om):
 
 
 @pytest.mark.parametrize("N,cp,Kd,mod", [(64, 16, 60, "QPSK"), (64, 16, 60, "BPSK"), (256, 18, 152, "16QAM"),
-                                         (1024, 72, 600, "64QAM"), (2048, 144, 1200, "QPSK"), (4096, 288, 2400, "16QAM")])
+                                         (1024, 72, 600, "64QAM"), (2048, 144, 1200, "QPSK"), (4096, 288, 2400, "16QAM"),
+                                         # from 1024-pt up the symbol is stored from registers, the prefix from the register slots that
+                                         # reach into the last cp samples: odd, one-sample, multi-slot and longer-than-N/2 prefixes
+                                         (1024, 73, 600, "16QAM"), (4096, 1, 2400, "QPSK"), (2048, 700, 1200, "64QAM"),
+                                         (2048, 1100, 1198, "16QAM"), (1024, 64, 1022, "QPSK")])
 def test_tx_chain_vs_oracle(om, N, cp, Kd, mod):
     rng = np.random.default_rng(N + len(mod))
     n_sym, n_frames = 8, 3
