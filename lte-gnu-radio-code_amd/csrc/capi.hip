@@ -167,9 +167,11 @@ struct ofdm_rx {
     int* pin_tsr = nullptr;              // [4] pinned host copy of s_tsr, written by the search kernel itself (tsr_host)
     int* pin_tsr_dev = nullptr;          //     its device address
     // GNU Radio sized buffers (a few symbols): a copy in the stream costs more than it moves (5-10 us of engine latency plus a
-    // 10-20 us bubble next to the kernels), so buffers up to PIN_BYTES go through pinned host memory that the kernels read and
+    // 10-20 us bubble next to the kernels), so buffers up to PIN_IN_BYTES / PIN_OUT_BYTES go through pinned host memory that the kernels read and
     // write in place over the link; the host's share is a memcpy of a few tens of KB
-    static constexpr size_t PIN_BYTES = size_t(256) << 10;
+    // (thresholds measured: input in place pays up to ~1 MB -- a 32-symbol buffer 0.107 -> 0.098 ms -- and loses at 4 MB, 0.21 ->
+    // 0.26-0.55 ms; output in place loses at 1.7 MB, 0.21 -> 0.275 ms)
+    static constexpr size_t PIN_IN_BYTES = size_t(1024) << 10, PIN_OUT_BYTES = size_t(256) << 10;
     cf* pin_in = nullptr;
     cf* pin_in_dev = nullptr;
     cf* pin_out = nullptr;
@@ -439,8 +441,8 @@ int ofdm_rx_create(const ofdm_rx_cfg* c, ofdm_rx** out) {
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_edf, rows * Kd);
     if (rc == OFDM_OK) rc = dev_alloc(&h->d_pack, rows * Kd);
     if (rc == OFDM_OK && (hipHostMalloc(reinterpret_cast<void**>(&h->pin_tsr), 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
-                          hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), ofdm_rx::PIN_BYTES, hipHostMallocMapped) != hipSuccess ||
-                          hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), ofdm_rx::PIN_BYTES, hipHostMallocMapped) != hipSuccess ||
+                          hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), ofdm_rx::PIN_IN_BYTES, hipHostMallocMapped) != hipSuccess ||
+                          hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), ofdm_rx::PIN_OUT_BYTES, hipHostMallocMapped) != hipSuccess ||
                           hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_tsr_dev), h->pin_tsr, 0) != hipSuccess ||
                           hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_in_dev), h->pin_in, 0) != hipSuccess ||
                           hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_out_dev), h->pin_out, 0) != hipSuccess))
@@ -707,8 +709,8 @@ int64_t ofdm_rx_work(ofdm_rx* h, const float* h_in, int64_t n_in, float* h_out, 
                 const bool shape_ok = int64_t(rows_ - n_del_) == n_data_symb && (h->count == 0 || n_data_symb * Kd <= n_out);
                 if (rows_ok && shape_ok && h->seg_armed) {
                     const size_t out_bytes = size_t(n_data_symb) * Kd * sizeof(cf);
-                    const bool in_place_in = size_t(n_in) * sizeof(cf) <= ofdm_rx::PIN_BYTES;
-                    const bool in_place_out = out_bytes <= ofdm_rx::PIN_BYTES;
+                    const bool in_place_in = size_t(n_in) * sizeof(cf) <= ofdm_rx::PIN_IN_BYTES;
+                    const bool in_place_out = out_bytes <= ofdm_rx::PIN_OUT_BYTES;
                     const cf* iq_dev = in_place_in ? h->pin_in_dev : h->d_in;
                     SyncArgs fa{};
                     fa.iq = iq_dev;
