@@ -651,29 +651,46 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
         int nb = (blk_on && !found) ? min(B, nvalid - P0) : 0;            // trials of this block (incl. the anchor)
         int nbx = (blk_on && !found) ? min(SG::MX * B, nvalid - P0) : 0;   // ... of the long block the cold test looks over
         int cand = 0x7fffffff;
+        bool long_ok = false;
+        float ucold = 3.0e38f;
         if (__syncthreads_or(nb > 1 ? 1 : 0)) {
             if constexpr (SG::MX > 1) {
                 // How far ahead is the long block worth looking?  From far away the sync symbol already shows in the anchor's lag
                 // vector at the alignments that will see it whole (the cp + 1 lags before its own): the long block ends where the
                 // first lag at half the anchor's own threshold would come within reach (a <= n - 1 + cp), so that the cold test
                 // below has a chance over all of it.  Only the amount of work depends on this guess, never a decision.
-                float ah = 3.0e38f;
+                float ah = 3.0e38f, um = 0.f;                           // um: the largest lag magnitude^2 BELOW that level
                 const float half2 = 0.25f * thr_k * e0;
 #pragma unroll
-                for (int q = 0; q < SG::KX; ++q)
-                    if (!(cnorm2(ux[q]) < half2)) ah = fminf(ah, float(t + T * q));
+                for (int q = 0; q < SG::KX; ++q) {
+                    const float m2 = cnorm2(ux[q]);
+                    if (!(m2 < half2))
+                        ah = fminf(ah, float(t + T * q));
+                    else
+                        um = fmaxf(um, m2);
+                }
                 ah = wave_min(ah);
-                if ((t & 63) == 0) blk[16 + (t >> 6)] = ah;
+                um = -wave_min(-um);
+                if ((t & 63) == 0) {
+                    blk[16 + (t >> 6)] = ah;
+                    blk[(t >> 6) * 4] = um;
+                }
                 wg_barrier();
+                um = 0.f;
 #pragma unroll
-                for (int w = 0; w < (T + 63) / 64; ++w) ah = fminf(ah, blk[16 + w]);
+                for (int w = 0; w < (T + 63) / 64; ++w) {
+                    ah = fminf(ah, blk[16 + w]);
+                    um = fmaxf(um, blk[w * 4]);
+                }
                 const int a_first = ah < 1.0e9f ? int(ah) : 0x3fffffff;
+                long_ok = a_first - cp >= nb;                            // the first hot lag lies outside the long block's reach
                 nbx = max(nb, min(nbx, a_first - cp));
-                wg_barrier();                                            // blk[16..] is read by everyone before the next anchor rewrites it
+                ucold = sqrtf(um) * (1.f + 1e-5f);                      // no lag the long block can reach starts above this
+                wg_barrier();                                            // blk[] is read by everyone before it is rewritten below
             }
             // window edges: xo[i] = x[w0 + i], xn[i] = x[w0 + N + i], w0 = P0 + cp;  i < nbx - 1
             const int64_t w0 = int64_t(P0) + cp;
-            float dw = 0.f, wadd = 0.f;
+            float dw = 0.f, wadd = 0.f, dlane = 0.f;
             cf da = cf{0.f, 0.f}, db = cf{0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < SG::RMAX; ++r) {
@@ -687,23 +704,28 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     wadd += cnorm2(n_);
                     da = da + (n_ - o);
                     db = db + cscale(o - n_, sgn);
+                    dlane += sqrtf(cnorm2(n_ - o));
                 }
             }
             SCAN_STAMP(2);                                                   // .. window-edge loads
             // inclusive scan of the per-lane totals over the T lanes of the slot (T <= 64: inside one wave; else via LDS)
-            float sw = dw, swa = wadd;
+            float sw = dw, swa = wadd, sd = dlane;
             cf sa = da, sb = db;
             constexpr int W = T < 64 ? T : 64;
+            constexpr bool PREFIX_D = SLOTS == 1 && SG::MX > 1;          // the |D| prefix feeds the long block's cold test only
 #pragma unroll
             for (int dlt = 1; dlt < W; dlt <<= 1) {
                 const float o1 = __shfl_up(sw, dlt, W), o2 = __shfl_up(swa, dlt, W);
                 const float o3 = __shfl_up(sa.x, dlt, W), o4 = __shfl_up(sa.y, dlt, W);
                 const float o5 = __shfl_up(sb.x, dlt, W), o6 = __shfl_up(sb.y, dlt, W);
+                float o7 = 0.f;
+                if constexpr (PREFIX_D) o7 = __shfl_up(sd, dlt, W);
                 if ((t & (W - 1)) >= dlt) {
                     sw += o1;
                     swa += o2;
                     sa = sa + cf{o3, o4};
                     sb = sb + cf{o5, o6};
+                    sd += o7;
                 }
             }
             float tot_add;
@@ -717,6 +739,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     r6[3] = sa.y;
                     r6[4] = sb.x;
                     r6[5] = sb.y;
+                    if constexpr (PREFIX_D) blk[(t >> 6) * 4 + 1] = sd;  // (the wave's |D| total: next to the scratch, not in it)
                 }
                 wg_barrier();
                 tot_add = 0.f;
@@ -728,6 +751,7 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                         sw += r6[0];
                         sa = sa + cf{r6[2], r6[3]};
                         sb = sb + cf{r6[4], r6[5]};
+                        if constexpr (PREFIX_D) sd += blk[w * 4 + 1];
                     }
                 }
             } else {
@@ -739,8 +763,11 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
             // anchor: E_0 = e0 (in band), N W_0 = e0 + |Y[0]|^2 + |Y[N/2]|^2, sum x = Y[0], sum (-1)^n x = Y[N/2]
             const float nw0 = e0 + cnorm2(y0) + cnorm2(yh);
             const float wbound = nw0 + float(N) * tot_add;               // >= N W_j for every j of the block
-            // this lane's share of {min_j thr_j, sum_i |D_i|} of the long block (x) and of its first block (b)
-            float my_tmin = 3.0e38f, my_dabs = 0.f, my_tminb = 3.0e38f, my_dabsb = 0.f;
+            // this lane's share of {min_j thr_j, sum_i |D_i|} of the first block, and the first trial of the long block that its
+            // own margin does not keep cold (below)
+            float my_tminb = 3.0e38f, my_dabsb = 0.f;
+            float sdrun = sd - dlane;                                    // sum of |D_i| before this lane's chunk
+            int my_fail = 0x7fffffff;
 #pragma unroll
             for (int r = 0; r < SG::RMAX; ++r) {
                 const int i = t * SG::RMAX + r;
@@ -759,43 +786,48 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     thr[i + 1] = th_;
                     xo[i] = n_ - o;                                      // dl[i] (this lane's own entry)
                     const float dm = sqrtf(cnorm2(n_ - o));
-                    my_tmin = fminf(my_tmin, th_);
-                    my_dabs += dm;
                     if (i < nb - 1) {
                         my_tminb = fminf(my_tminb, th_);
                         my_dabsb += dm;
                     }
+                    if constexpr (PREFIX_D) {
+                        // trial j = i + 1 stays cold if sqrt(thr_j) - max|G| * sum_{i' <= i} |D_i'| still clears every lag it can see
+                        sdrun += dm;
+                        const float margin = sqrtf(fmaxf(th_, 0.f)) - sdrun * gmax * (1.f + 1e-4f);
+                        if ((!(th_ > 0.f) || !(margin > ucold)) && my_fail == 0x7fffffff) my_fail = i + 1;
+                    }
                 }
             }
             if constexpr (SLOTS == 1) {
-                my_tmin = wave_min(my_tmin);
-                my_dabs = wave_sum(my_dabs);
                 my_tminb = wave_min(my_tminb);
                 my_dabsb = wave_sum(my_dabsb);
+                const float ff = wave_min(float(min(my_fail, 1 << 24)));      // (exact in a float)
                 if ((t & 63) == 0) {
                     float* b4 = blk + (t >> 6) * 4;
-                    b4[0] = my_tmin;
-                    b4[1] = my_dabs;
+                    b4[0] = ff;
                     b4[2] = my_tminb;
                     b4[3] = my_dabsb;
                 }
             }
-            // Cold blocks.  c_{P0+j}[d] = c_{P0}[d + j] + sum_{i<j} D_i G[.] exactly, so over a WHOLE block no correlation value can
-            // rise above |u_a(0)| + max|G| * sum_i |D_i|.  Where that stays below the block's lowest threshold for every alignment
-            // the block can reach (a <= n - 1 + cp), no trial of the block can be flagged -- let alone accepted: the thresholds sit
-            // 2e-4 below the gate -- and the block is skipped WITHOUT running the recurrence.  The test needs nothing but the
-            // anchor's lag vector, so it is made over MX blocks first (one anchor per MX * B trials far from the sync) and, if
-            // that fails, over the first block alone.  Weak-energy trials (thr < 0) and blocks near the sync fail both and take
-            // the screened recurrence below, exactly as before.
+            // Cold blocks.  c_{P0+j}[d] = c_{P0}[d + j] + sum_{i<j} D_i G[.] exactly, so at trial j no correlation value can lie
+            // above |u_a(0)| + max|G| * sum_{i<j} |D_i|.  Where that stays below the trial's threshold for every alignment in
+            // reach, the trial cannot be flagged -- let alone accepted: the thresholds sit 2e-4 below the gate -- and needs no
+            // recurrence.  Over the long block (up to MX * B trials, ending before the first lag at half the anchor's threshold
+            // comes within reach) this is decided TRIAL BY TRIAL with the running sum of |D| and the trial's own threshold against
+            // the largest lag below that level: the trials before the first one that fails are skipped, however many they are (the
+            // running sum eats the margin after ~500 trials at 2048-pt; testing whole blocks against their lowest threshold and
+            // their total sum, as the first version did, skipped 240 where this skips 480-550: profiles/r03_sync_leads.txt).  If
+            // that does not reach past the first block, the first block alone is tested by its totals against every lag it can
+            // see.  Weak-energy trials (thr < 0) and blocks near the sync fail both and take the screened recurrence below.
             bool run_block = true;
             if constexpr (SLOTS == 1) {
                 wg_barrier();                                            // blk[] and the thresholds are written
-                auto cold = [&](int which, int n_tr) {
+                auto cold = [&](int n_tr) {                              // the first block, by its totals
                     float tmin_b = 3.0e38f, dtot = 0.f;
 #pragma unroll
                     for (int w = 0; w < (T + 63) / 64; ++w) {
-                        tmin_b = fminf(tmin_b, blk[w * 4 + 2 * which]);
-                        dtot += blk[w * 4 + 2 * which + 1];
+                        tmin_b = fminf(tmin_b, blk[w * 4 + 2]);
+                        dtot += blk[w * 4 + 3];
                     }
                     const float room = sqrtf(fmaxf(tmin_b, 0.f)) - dtot * gmax * (1.f + 1e-5f);
                     bool hot = !(tmin_b > 0.f) || !(room > 0.f);
@@ -804,10 +836,19 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_scan_kernel(RxDev r
                     for (int q = 0; q < SG::KX; ++q) hot |= (t + T * q <= n_tr - 1 + cp) && !(cnorm2(ux[q]) < lim2);
                     return __syncthreads_or(hot ? 1 : 0) == 0;
                 };
-                if (nbx > nb && cold(0, nbx)) {
-                    nb = nbx;                                            // the long block is cold: skip all of it
+                int n_cold = 0;                                          // trials 1 .. n_cold - 1 of the long block are proven cold
+                if constexpr (SG::MX > 1) {
+                    if (long_ok && nbx > nb) {
+                        float ff = 3.0e38f;
+#pragma unroll
+                        for (int w = 0; w < (T + 63) / 64; ++w) ff = fminf(ff, blk[w * 4]);
+                        n_cold = min(int(ff), nbx);
+                    }
+                }
+                if (n_cold > nb) {
+                    nb = n_cold;                                         // skip them all; the next anchor is the first trial not proven
                     run_block = false;
-                } else if (cold(1, nb)) {
+                } else if (cold(nb)) {
                     run_block = false;
                 }
             }
