@@ -433,6 +433,9 @@ __global__ void __launch_bounds__(Plan<N>::WG, MINW) rx_sync_kernel(RxDev rx, Sy
 // than the recurrence can drift over one block (<= 256 steps of ~6e-8 relative rounding), so the accepted trial and its
 // lag are those of the exhaustive search.  Frames whose sync sits at trial 0 never enter the recurrence.
 // Preconditions checked by the host: S == 1, stride == 1, Ks == N - 2, no rotator, B + cp <= SCAN_QM * T.
+#ifndef OFDM_SCAN_MX_T256
+#define OFDM_SCAN_MX_T256 5
+#endif
 template <int N>
 struct ScanGeom {
     static constexpr int T = Plan<N>::T;
@@ -440,7 +443,7 @@ struct ScanGeom {
     static constexpr int BMAX = (QM * T < 256) ? QM * T : 256;        // longest block (trials per anchor) the recurrence walks
     // The cold-block test (below) needs no recurrence state, only the anchor's lag vector: where one frame owns the workgroup it
     // looks MX blocks ahead, so a frame whose sync lies far away pays one anchor per MX * B trials.
-    static constexpr int MX = (T >= 128) ? 3 : (T >= 64) ? 2 : 1;     // (two at 1024-pt: three would spill)
+    static constexpr int MX = (T >= 256) ? OFDM_SCAN_MX_T256 : (T >= 128) ? 3 : (T >= 64) ? 2 : 1;     // (two at 1024-pt: three would spill)
     static constexpr int BX = MX * BMAX;                              // window-edge samples / thresholds held per anchor
     static constexpr int KX = MX * QM;                                // lag values per lane the anchor keeps (alignments a < KX * T)
     static_assert(KX <= Plan<N>::P, "the anchor's inverse FFT holds P lags per lane");
@@ -1429,6 +1432,11 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
             // SYNC_STAGE_SEGS segments go first; the rest are launched behind them and, when the hit is already published,
             // only take their tickets.  Same decisions: the tickets and the published minimum span both launches.
             if (a.seg_base < 0 || a.seg_launch < 0 || a.seg_base % Plan<N>::SLOTS) return hipErrorInvalidValue;
+            if constexpr (ScanGeom<N>::BYTES > 65536) {
+                static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>),
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ScanGeom<N>::BYTES));
+                if (once != hipSuccess) return once;
+            }
             SyncArgs st = a;
             int base = a.seg_base;
             const int end = a.seg_launch > 0 ? std::min(a.n_seg, a.seg_base + a.seg_launch) : a.n_seg;
@@ -1449,6 +1457,11 @@ static hipError_t launch_sync_n(const RxDev& rx, const SyncArgs& a, hipStream_t 
                 hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW, true>), dim3(1), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, st);
             }
             return hipGetLastError();
+        }
+        if constexpr (ScanGeom<N>::BYTES > 65536) {                  // (a compile-time size: announced once)
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_sync_scan_kernel<N, OFDM_SCAN_MINW>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ScanGeom<N>::BYTES));
+            if (once != hipSuccess) return once;
         }
         hipLaunchKernelGGL((rx_sync_scan_kernel<N, OFDM_SCAN_MINW>), dim3(grid), dim3(Plan<N>::WG), ScanGeom<N>::BYTES, s, rx, a);
         return hipGetLastError();

@@ -1,0 +1,4 @@
+for rep in 1 2; do for l in lte-gnu-radio-code_amd/ofdm_mi355x/libofdm_mi355x.so tools/experiments/libofdm_g_mx3.so tools/experiments/libofdm_g_mx7.so; do
+  OFDM_MI355X_LIB=$l python bench.py --config n4096 --lead random --no-cpu --no-probes --steps 100 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']
+print('$l'.split('/')[-1], 'sync_ms %.4f demod_ms %.4f ms/step %.4f ber %.3g' % (r['sync_kernel_ms'], r['kernel_ms'], j['ms_per_step'], j['config']['bit_error_rate_frame0']))"; done; done
