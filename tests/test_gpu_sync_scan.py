@@ -99,6 +99,39 @@ def test_random_leads_match_the_oracle(om, N, cp, Kd, n_sym, n_frames, sigma, ma
     assert len(hits) > min(4, n_frames - 2)                    # the search really ended at different trials
 
 
+@pytest.mark.parametrize("N,cp,Kd,n_sym,n_frames,gate,taps", [
+    (1024, 72, 600, 8, 120, 0.7, "ref"), (2048, 144, 1200, 8, 160, 0.7, "delay"), (2048, 144, 1200, 8, 96, 0.3, "rayleigh"),
+    (2048, 144, 1200, 8, 96, 0.7, "rayleigh"), (4096, 288, 2400, 4, 64, 0.7, "delay"), (4096, 288, 2400, 4, 48, 0.3, "rayleigh")])
+def test_dense_lead_sweep_screened_equals_exhaustive(om, N, cp, Kd, n_sym, n_frames, gate, taps):
+    """The skip of cold stretches is decided trial by trial from the anchor's lag vector: how far it carries depends on where the
+    sync lies relative to the anchor, on the channel and on the gate.  Frames with leads spread evenly over 0 ... 2.1 L (anchors
+    at every phase of the approach, long skips, skips that end a few trials short, peaks inside the first block), a one-sample
+    delay / the reference taps / an 8-tap Rayleigh draw, gate 0.7 and 0.3: decisions identical to the exhaustive search, arrays
+    to 2e-6 (the exhaustive kernel is pinned to the oracle above)."""
+    L = N + cp
+    rng = np.random.default_rng(N + n_frames)
+    leads = np.linspace(0, 2.1 * L, n_frames).astype(int) + rng.integers(0, 5, n_frames)
+    leads[0] = 0
+    if taps == "ref":
+        h = orc.REF_TAPS
+    elif taps == "delay":
+        h = np.array([0.0, 1.0])
+    else:
+        h = (rng.standard_normal(8) + 1j * rng.standard_normal(8)) * np.exp(-0.4 * np.arange(8))
+    n_sym_tx = n_sym + 4                                       # the late frames still hold whole patterns
+    bits, iq = _frames_with_leads(N, cp, Kd, n_sym_tx, leads, 0.03, seed=N + 7, taps=h)
+    rx = om.RxEngine(n_sym_tx, N, cp, N - 2, (1, 3), Kd, 30, gate)
+    eq_s, b_s, tsr_s, H_s = _run(om, rx, iq, Kd, exhaustive=False)
+    eq_x, b_x, tsr_x, H_x = _run(om, rx, iq, Kd, exhaustive=True)
+    assert np.array_equal(tsr_s, tsr_x), np.nonzero((tsr_s != tsr_x).any(axis=1))[0]
+    assert np.array_equal(b_s, b_x)
+    fin = np.isfinite(eq_x)
+    assert np.array_equal(fin, np.isfinite(eq_s))
+    assert relerr(np.where(fin, eq_s, 0), np.where(fin, eq_x, 0)) < 2e-6 and relerr(H_s, H_x) < 2e-6
+    assert tsr_s[:, 3].sum() >= n_frames - 2                   # (a Rayleigh draw may leave a frame below the gate in both searches)
+    assert len(set(tsr_s[:, 0].tolist())) > n_frames // 2
+
+
 def test_zero_leads_noise_only_frames_and_trial_cap(om):
     """Leads of exact zeros (the window energy is 0: the screen must hand those trials to the exact evaluation), a frame of pure
     noise (no sync anywhere), and a trial cap below some frames' sync position: identical to the exhaustive search and to the
