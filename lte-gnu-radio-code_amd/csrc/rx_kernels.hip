@@ -1040,7 +1040,7 @@ __global__ void __launch_bounds__(256) bit_errors_kernel(const uint8_t* a, const
 
 hipError_t launch_bit_errors(const uint8_t* a, const uint8_t* b, int64_t n, unsigned long long* count, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    const int64_t blocks = std::min<int64_t>((n / 16 + 255) / 256 + 1, 2048);
+    const int64_t blocks = std::min<int64_t>((n / 16 + 255) / 256 + 1, 65536);
     hipLaunchKernelGGL(bit_errors_kernel, dim3(unsigned(blocks)), dim3(256), 0, s, a, b, n, count);
     return hipGetLastError();
 }
@@ -1584,6 +1584,15 @@ hipError_t launch_rx_chan_time(const RxDev& rx, const cf* H, cf* htime, int n_ro
     return hipErrorInvalidValue;
 }
 
+// Grid caps of the two passes.  These kernels loop with the grid as stride; with the 4 096 workgroups (16 per CU) of rounds 1-2 they
+// read 0.60-0.68 of the HBM rate, with up to 262 144 (the loop then runs once or twice) 0.68-0.82: the dispatcher keeps more loads in
+// flight across many short workgroups than 16 long ones per CU do (profiles/r03_demap_grid_ab.txt).
+#ifndef OFDM_DEMAP_CAP1
+#define OFDM_DEMAP_CAP1 262144
+#endif
+#ifndef OFDM_DEMAP_CAP2
+#define OFDM_DEMAP_CAP2 262144
+#endif
 hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     const bool soft = a.soft0 || a.soft1;
@@ -1595,7 +1604,7 @@ hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
     }
     // pass 1 (one read of the symbols): hard bits and / or the distance sums sigma needs
     if (a.hard || soft) {
-        const unsigned g1 = unsigned(std::min<int64_t>((a.n / 4 + 255) / 256 + 1, 4096));
+        const unsigned g1 = unsigned(std::min<int64_t>((a.n / 4 + 255) / 256 + 1, OFDM_DEMAP_CAP1));
 #define OFDM_P1(M)                                                                                             \
     do {                                                                                                       \
         if (a.hard && soft)                                                                                    \
@@ -1615,13 +1624,13 @@ hipError_t launch_demap(const DemapArgs& a, hipStream_t s) {
     }
     // pass 2 (second read): the two metric arrays
     if (soft) {
-        const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, 4096));
+        const unsigned grid = unsigned(std::min<int64_t>((a.n + 255) / 256, OFDM_DEMAP_CAP2));
         if (a.mod == 2)
             hipLaunchKernelGGL(demap_soft_kernel, dim3(grid), dim3(256), 0, s, a);
         else if (a.mod == 4)
             hipLaunchKernelGGL(demap_soft_qam_kernel<4>, dim3(grid), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(demap_soft_qam64_kernel, dim3(unsigned(std::min<int64_t>(a.n / 512 + 1, 4096))), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(demap_soft_qam64_kernel, dim3(unsigned(std::min<int64_t>(a.n / 512 + 1, OFDM_DEMAP_CAP2))), dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

@@ -661,11 +661,20 @@ __global__ void __launch_bounds__(256) probe_kernel(const float4* __restrict__ i
     }
 }
 
+// Grid of the two probes: as many workgroups as there is work (one unrolled trip per thread / one symbol per workgroup).  With the
+// 16 384 / 8 192 looping workgroups of rounds 1-2 the copy read 5.2-5.9 TB/s and the pattern 5.9-6.2 where these read 6.0-6.4 and
+// 6.3-6.4 on the same chip: the probes are the yardstick the demod kernel is held against, so they get the better grid.
+#ifndef OFDM_PROBE_CAP0
+#define OFDM_PROBE_CAP0 4194304
+#endif
+#ifndef OFDM_PROBE_CAP1
+#define OFDM_PROBE_CAP1 4194304
+#endif
 hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sym_in16, int gap16, int sym_out16, int64_t n_sym,
                         hipStream_t s) {
     const size_t lds = size_t(mode >> 4) * 1024;      // occupancy experiment: mode = base + 16 * KiB of (unused) dynamic LDS
     mode &= 15;
-    const unsigned grid = mode == 0 ? 256 * 64 : unsigned(std::min<int64_t>(n_sym, 256 * 32));
+    const unsigned grid = mode == 0 ? unsigned(std::max<int64_t>(256, std::min<int64_t>((n16 / 4 + 255) / 256, OFDM_PROBE_CAP0))) : unsigned(std::min<int64_t>(n_sym, OFDM_PROBE_CAP1));
     hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(256), lds, s, static_cast<const float4*>(in), static_cast<float4*>(out), n16, mode,
                        sym_in16, gap16, sym_out16, n_sym);
     return hipGetLastError();
@@ -733,20 +742,20 @@ hipError_t launch_tx_modulate(const TxDev& tx, const ModArgs& a, hipStream_t s) 
 hipError_t launch_tx_random_bits(uint64_t seed, uint64_t offset, uint8_t* out, int64_t n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int64_t nblk = (n + 127) / 128 + 1;
-    hipLaunchKernelGGL(tx_random_bits_kernel, dim3(unsigned(std::min<int64_t>((nblk + 255) / 256, 4096))), dim3(256), 0, s, seed, offset, out, n);
+    hipLaunchKernelGGL(tx_random_bits_kernel, dim3(unsigned(std::min<int64_t>((nblk + 255) / 256, 262144))), dim3(256), 0, s, seed, offset, out, n);
     return hipGetLastError();
 }
 
 hipError_t launch_tx_map(const uint8_t* bits, int bits_mode, int bps, int64_t n_sym, cf* out, hipStream_t s) {
     if (n_sym <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tx_map_kernel, dim3(unsigned(std::min<int64_t>((n_sym + 255) / 256, 8192))), dim3(256), 0, s, bits, bits_mode, bps, n_sym, out);
+    hipLaunchKernelGGL(tx_map_kernel, dim3(unsigned(std::min<int64_t>((n_sym + 255) / 256, 262144))), dim3(256), 0, s, bits, bits_mode, bps, n_sym, out);
     return hipGetLastError();
 }
 
 hipError_t launch_tx_grid(const TxDev& tx, const GridArgs& a, hipStream_t s) {
     if (a.n_rows <= 0) return hipSuccess;
     const int64_t total = a.n_rows * tx.nfft;
-    hipLaunchKernelGGL(tx_grid_kernel, dim3(unsigned(std::min<int64_t>((total + 255) / 256, 16384))), dim3(256), 0, s, tx, a);
+    hipLaunchKernelGGL(tx_grid_kernel, dim3(unsigned(std::min<int64_t>((total + 255) / 256, 262144))), dim3(256), 0, s, tx, a);
     return hipGetLastError();
 }
 
