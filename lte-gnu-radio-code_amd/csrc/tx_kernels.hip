@@ -680,6 +680,9 @@ hipError_t launch_probe(const void* in, void* out, int64_t n16, int mode, int sy
     return hipGetLastError();
 }
 
+#ifndef OFDM_TX_GRID_MULT
+#define OFDM_TX_GRID_MULT 16
+#endif
 template <int N, int KIND>
 static hipError_t launch_mod_nk(const TxDev& tx, const ModArgs& a, hipStream_t s) {
     const int64_t units = int64_t(a.n_frames) * a.n_sym;
@@ -700,7 +703,11 @@ static hipError_t launch_mod_nk(const TxDev& tx, const ModArgs& a, hipStream_t s
             n_cu = prop.multiProcessorCount;
         per_cu = nb;
     }
-    int64_t g0 = std::min<int64_t>(wgs, int64_t(n_cu) * per_cu);
+    // ... unless the launch is large enough for MANY such waves of workgroups: then the tail is a sixteenth of the work and the
+    // dispatcher's refilling of freed slots beats the fixed assignment (+2-8 % at the bench's batch sizes; a workgroup still walks
+    // >= 16 symbols, so its tables stay amortised; at 512 frames the exactly-resident grid is as good or better and is kept)
+    const int64_t resident = int64_t(n_cu) * per_cu;
+    int64_t g0 = std::min<int64_t>(wgs, wgs >= resident * OFDM_TX_GRID_MULT * 16 ? resident * OFDM_TX_GRID_MULT : resident);
     // a workgroup walks units first, first + stride, ...: with a stride that is a multiple of the [S, D] pattern length it would
     // meet the same position of the pattern every time (a quarter of the workgroups only copying sync symbols): keep them coprime
     if (g0 < wgs) {
