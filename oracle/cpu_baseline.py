@@ -2,7 +2,7 @@
 """CPU baseline leg of bench.py (TEST/MEASUREMENT INFRASTRUCTURE, never on the product path).
 
 Runs in its own process (no GPU state) on a bounded sample of the bench workload saved as .npy (whole frames of the batch
-that was just timed on the GPU).  Three legs, BASELINE.md section 3 / SURVEY.md section 8(d):
+that was just timed on the GPU).  Four legs, BASELINE.md section 3 / SURVEY.md section 8(d):
 
  (i)   port        `rx_work_faithful_ops`: the reference block's OPERATION STRUCTURE (dense diag matmuls, per-symbol
                    np.fft.fft, Python loops) on whole 240-symbol frames, one frame after the other until the time budget is
@@ -13,6 +13,7 @@ that was just timed on the GPU).  Three legs, BASELINE.md section 3 / SURVEY.md 
                    >= 3 repetitions over >= 8 frames per worker, median reported.
  (iii) c_scalar    oracle/ofdm_oracle_c.c: the plain-C double-precision scalar restatement (sync search + LS estimate + demod of
                    a whole frame), single thread -- what one core does without NumPy's per-call overheads.
+ (iv)  c_parallel  the same C on every usable core (OpenMP over frames, >= 8 frames per thread, 3 repetitions, median).
 
 Prints one JSON object (flat keys, short strings).
 """
@@ -145,6 +146,25 @@ def main():
         c_rate, c_frames, c_dt = None, 0, 0.0
         sys.stderr.write("cpu_baseline: C leg skipped (%s: %s)\n" % (type(e).__name__, e))
 
+    # ---- (iv) the same plain C on every usable core (OpenMP over frames, >= 8 frames per thread), three repetitions, median
+    cpar_rate = cpar_min = cpar_max = None
+    cpar_frames = 0
+    try:
+        from oracle import oracle_c
+        cpar_frames = min(n_avail, cores * FRAMES_PER_WORKER)
+        block = np.ascontiguousarray(iq[:cpar_frames])
+        oracle_c.rx_work_frames(block[:cores], n_sym, N, cp, N - 2, (1, 3), Kd, snr, gate, n_threads=cores)      # warm-up
+        rates = []
+        for _ in range(VEC_REPS):
+            t0 = time.perf_counter()
+            tsr_all, hits = oracle_c.rx_work_frames(block, n_sym, N, cp, N - 2, (1, 3), Kd, snr, gate, n_threads=cores)
+            rates.append(cpar_frames * frame_len / (time.perf_counter() - t0) / 1e6)
+            assert hits == cpar_frames and (tsr_all[:, 0] == cp).all()
+        rates.sort()
+        cpar_rate, cpar_min, cpar_max = rates[len(rates) // 2], rates[0], rates[-1]
+    except Exception as e:
+        sys.stderr.write("cpu_baseline: parallel C leg skipped (%s: %s)\n" % (type(e).__name__, e))
+
     # ---- (ii) vectorised NumPy, one worker per usable core, warmed before the clock
     ocfg = dict(nfft=N, cp_len=cp, synch_dat=(1, 3), num_synch_bins=N - 2, num_data_bins=Kd, snr=snr, scale_factor_gate=gate)
     per = FRAMES_PER_WORKER
@@ -178,7 +198,11 @@ def main():
         vectorised_cores=int(workers), vectorised_reps=int(VEC_REPS), vectorised_frames_per_worker=int(per),
         vectorised_sample="%d workers x %d %sframes x %d reps, warmed, median" % (workers, per, "disjoint " if disjoint else "", VEC_REPS),
         c_scalar_value=None if c_rate is None else round(c_rate, 2), c_scalar_cores=1,
-        c_scalar_sample="%d frames x %d symbols, plain C fp64, 1 thread, %.1f s" % (c_frames, n_sym, c_dt))))
+        c_scalar_sample="%d frames x %d symbols, plain C fp64, 1 thread, %.1f s" % (c_frames, n_sym, c_dt),
+        c_parallel_value=None if cpar_rate is None else round(cpar_rate, 2),
+        c_parallel_min=None if cpar_min is None else round(cpar_min, 2), c_parallel_max=None if cpar_max is None else round(cpar_max, 2),
+        c_parallel_cores=int(cores),
+        c_parallel_sample="%d frames x %d symbols, plain C fp64, %d OpenMP threads, %d reps, median" % (cpar_frames, n_sym, cores, VEC_REPS))))
 
 
 if __name__ == "__main__":

@@ -239,3 +239,31 @@ int ofdm_oracle_c_rx_work(const float* in0, int64_t n_in, int N, int cp, int Ks,
 }
 
 int ofdm_oracle_c_version(void) { return 1; }
+
+/* The same over n_frames independent buffers (fresh instance each), frames dealt to n_threads OpenMP threads: the CPU baseline's
+ * "every usable core of the host in plain C" leg.  tsr [n_frames][3]; the estimate and the data rows of a frame are computed and
+ * dropped (the caller times throughput; parity is checked through the single-frame entry).  Returns the number of frames whose sync
+ * was found, < 0 on error. */
+int ofdm_oracle_c_rx_work_frames(const float* in0, int64_t n_frames, int64_t frame_len, int N, int cp, int Ks, int Kd, int S, int D,
+                                 double snr, double gate, int n_rows, double* tsr, int n_threads) {
+    int err = 0, hits = 0;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1) reduction(+ : hits)
+    for (int64_t f = 0; f < n_frames; ++f) {
+        double* chan = malloc(sizeof(double) * 2 * (size_t)N);
+        double* data = malloc(sizeof(double) * 2 * (size_t)n_rows * (size_t)Kd);
+        int rc = -1;
+        if (chan && data)
+            rc = ofdm_oracle_c_rx_work(in0 + 2 * f * frame_len, frame_len, N, cp, Ks, Kd, S, D, snr, gate, n_rows, tsr + 3 * f, chan, data);
+        if (rc < 0) {
+#pragma omp atomic write
+            err = rc;
+        } else if (tsr[3 * f] != 0.0 || tsr[3 * f + 2] != 0.0) {
+            hits += 1;
+        }
+        free(chan);
+        free(data);
+    }
+    return err < 0 ? err : hits;
+}
+

@@ -46,3 +46,22 @@ def rx_work(iq, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data
     if rc < 0:
         raise RuntimeError("ofdm_oracle_c_rx_work failed: %d" % rc)
     return tsr, chan, data, rc
+
+
+def rx_work_frames(iq, num_ofdm_symb, nfft, cp_len, num_synch_bins, synch_dat, num_data_bins, snr, gate=0.7, n_threads=1):
+    """`rx_work` over the rows of iq [n_frames, frame_len] (a fresh instance per frame) on n_threads OpenMP threads.
+    Returns (time_synch_ref [n_frames, 3], frames with a detection).  Throughput leg of the CPU baseline."""
+    lib = load()
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    n_frames, frame_len = iq.shape
+    tsr = np.zeros((n_frames, 3))
+    fn = lib.ofdm_oracle_c_rx_work_frames
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                   C.c_int, C.c_void_p, C.c_int]
+    rc = fn(iq.ctypes.data, n_frames, frame_len, nfft, cp_len, num_synch_bins, num_data_bins, int(synch_dat[0]), int(synch_dat[1]),
+            float(snr), float(gate), num_ofdm_symb, tsr.ctypes.data, int(n_threads))
+    if rc < 0:
+        raise RuntimeError("ofdm_oracle_c_rx_work_frames failed: %d" % rc)
+    return tsr, rc
+

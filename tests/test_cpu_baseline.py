@@ -1,6 +1,6 @@
-"""The CPU-baseline child of bench.py on a tiny workload (CPU only): all three legs run, the line carries what SURVEY 8(d) /
+"""The CPU-baseline child of bench.py on a tiny workload (CPU only): all four legs run, the line carries what SURVEY 8(d) /
 BASELINE.md section 3 ask for (host cores, usable cores, >= 3 timed repetitions of warmed workers, whole frames of >= 240 symbols
-for the reference-structure leg, the plain-C scalar leg)."""
+for the reference-structure leg, the plain-C scalar leg and the same C on every usable core)."""
 import json
 import os
 import subprocess
@@ -23,7 +23,7 @@ def test_usable_cores_respects_affinity_and_override(monkeypatch):
     assert cb.sample_frames_wanted() == max(16, 3 * cb.FRAMES_PER_WORKER)
 
 
-def test_cpu_baseline_child_runs_all_three_legs(tmp_path):
+def test_cpu_baseline_child_runs_all_legs(tmp_path):
     N, cp, Kd, n_sym = 64, 16, 60, 240
     rng = np.random.default_rng(1)
     frames = []
@@ -43,3 +43,4 @@ def test_cpu_baseline_child_runs_all_three_legs(tmp_path):
     assert d["vectorised_reps"] >= 3 and d["vectorised_frames_per_worker"] >= 8 and d["vectorised_value"] > 0
     assert "240 symbols" in d["sample"] and "disjoint" in d["vectorised_sample"]
     assert d["c_scalar_value"] and d["c_scalar_cores"] == 1
+    assert d["c_parallel_value"] and d["c_parallel_cores"] == 2 and "OpenMP" in d["c_parallel_sample"]

@@ -61,3 +61,22 @@ def test_c_restatement_guard_zero_rows_and_padding():
         assert relerr(edf, rx.est_data_freq) < 1e-10
     with pytest.raises(IndexError):
         oracle_c.rx_work(x, 4, N, cp, N - 2, (1, 3), Kd, 30, 0.7)
+
+
+def test_c_oracle_frames_entry_equals_the_single_frame_entry():
+    """The OpenMP multi-frame entry (CPU baseline, every usable core) returns the single-frame entry's sync reference per frame."""
+    from oracle import oracle_c
+    N, cp, Kd, n_sym = 64, 16, 60, 8
+    rng = np.random.default_rng(3)
+    frames = []
+    for lead in (0, 5, 33):
+        tx = orc.channel_apply(orc.tx_modulate(rng.integers(0, 2, 6 * Kd * 2), N, cp, N - 2, Kd, n_sym), orc.REF_TAPS, N)
+        x = np.concatenate([0.01 * (rng.standard_normal(lead) + 1j * rng.standard_normal(lead)), tx])[:n_sym * (N + cp)]
+        frames.append(np.concatenate([x, np.zeros(n_sym * (N + cp) - len(x))]).astype(np.complex64))
+    iq = np.stack(frames)
+    tsr, hits = oracle_c.rx_work_frames(iq, n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7, n_threads=2)
+    assert hits == 3
+    for f in range(3):
+        t1, _, _, _ = oracle_c.rx_work(iq[f], n_sym, N, cp, N - 2, (1, 3), Kd, 100, 0.7)
+        assert np.array_equal(tsr[f], t1)
+
