@@ -151,7 +151,7 @@ def _profiled():
 
 def cpu_baseline(cfg, d_rx, fl):
     """oracle/cpu_baseline.py in a fresh child process (no GPU state) on a bounded sample of this workload: whole frames of the
-    batch that was just timed, >= 8 per usable host core for the vectorised leg (oracle/cpu_baseline.py names its three legs)."""
+    batch that was just timed, >= 8 per usable host core for the vectorised leg (oracle/cpu_baseline.py names its four legs)."""
     import tempfile
     from oracle import cpu_baseline as cb
     n = min(int(d_rx.shape[0]), cb.sample_frames_wanted())
